@@ -1,0 +1,75 @@
+# Build of the MI355X-native GPU monitoring stack.
+#   make            -> build/libgpumon.so, build/bin/{gpumon,gpumon-exporter,gpumon-hostengine,gpumon-pod-exporter}
+#   make diag       -> build/libgpumon_diag.so (HIP kernels, --offload-arch=gfx950) + build/bin/gpumon-diag
+#   make tsan|asan  -> sanitizer builds of the core + C++ tests (CPU, fake backend)
+#   make test       -> C++ unit tests
+ROCM      ?= /opt/rocm
+CXX       ?= g++
+HIPCC     ?= $(ROCM)/bin/hipcc
+ARCH      ?= gfx950
+BUILD     ?= build
+SAN       ?=
+OPT       ?= -O2
+CXXFLAGS  += -std=c++17 $(OPT) -g -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-missing-field-initializers \
+             -fvisibility=hidden -pthread -Iinclude -I$(ROCM)/include $(SAN)
+LDFLAGS   += -pthread -ldl $(SAN)
+
+CORE_SRC := core/common/util.cc core/common/json.cc core/fields.cc \
+            core/backend/fake_backend.cc core/backend/amdsmi_backend.cc \
+            core/engine/engine.cc core/engine/health.cc core/engine/policy.cc core/engine/accounting.cc \
+            core/rpc/wire.cc core/rpc/server.cc core/rpc/client.cc \
+            core/exporter/http.cc core/exporter/exporter.cc core/exporter/podmap.cc core/exporter/kubelet.cc \
+            core/exporter/views.cc core/exporter/rest.cc core/exporter/pod_exporter.cc core/capi.cc
+CORE_OBJ := $(CORE_SRC:%.cc=$(BUILD)/obj/%.o)
+BINS     := gpumon gpumon-exporter gpumon-hostengine gpumon-pod-exporter
+DIAG_HIP := diag/hip/hbm_stream.hip diag/hip/memtest.hip diag/hip/mfma_gemm.hip diag/hip/diag_api.hip
+DIAG_OBJ := $(DIAG_HIP:%.hip=$(BUILD)/obj/%.o)
+HIPFLAGS += --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Idiag -Wno-unused-result
+
+.PHONY: all core bins diag test tsan asan clean
+all: core bins
+core: $(BUILD)/libgpumon.so
+bins: $(BINS:%=$(BUILD)/bin/%)
+
+$(BUILD)/obj/%.o: %.cc
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS) -MMD -MP -c $< -o $@
+
+$(BUILD)/libgpumon.so: $(CORE_OBJ)
+	$(CXX) -shared -o $@ $^ $(LDFLAGS)
+
+$(BUILD)/bin/%: cmd/%.cc $(BUILD)/libgpumon.so
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS) -fvisibility=default -o $@ $< -L$(BUILD) -lgpumon -Wl,-rpath,'$$ORIGIN/..' $(LDFLAGS)
+
+# ---- active diagnostics: hand-written CDNA4 kernels --------------------------
+$(BUILD)/obj/%.o: %.hip
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+diag: $(BUILD)/libgpumon_diag.so $(BUILD)/bin/gpumon-diag
+$(BUILD)/libgpumon_diag.so: $(DIAG_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
+
+$(BUILD)/bin/gpumon-diag: cmd/gpumon-diag.cc diag/rccl/rccl_sweep.cc $(BUILD)/libgpumon_diag.so $(BUILD)/libgpumon.so
+	@mkdir -p $(dir $@)
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -Idiag -o $@ cmd/gpumon-diag.cc diag/rccl/rccl_sweep.cc \
+	    -L$(BUILD) -lgpumon_diag -lgpumon -Wl,-rpath,'$$ORIGIN/..' -ldl -pthread
+
+# ---- tests -------------------------------------------------------------------
+TESTS := $(patsubst tests/cpp/%.cc,$(BUILD)/tests/%,$(wildcard tests/cpp/*.cc))
+$(BUILD)/tests/%: tests/cpp/%.cc $(BUILD)/libgpumon.so
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS) -fvisibility=default -I. -o $@ $< $(CORE_OBJ) $(LDFLAGS)
+test: $(TESTS)
+	@for t in $(TESTS); do echo "== $$t"; $$t || exit 1; done
+
+tsan:
+	$(MAKE) BUILD=build-tsan SAN="-fsanitize=thread" OPT=-O1 test
+asan:
+	$(MAKE) BUILD=build-asan SAN="-fsanitize=address,undefined -fno-omit-frame-pointer" OPT=-O1 test
+
+clean:
+	rm -rf build build-tsan build-asan
+
+-include $(CORE_OBJ:.o=.d)

@@ -1,0 +1,406 @@
+#include "exporter.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "../common/util.h"
+
+namespace gpumon {
+namespace {
+
+struct Member {
+  uint16_t field;
+  const char* label;  // extra label name or nullptr
+  std::string label_value;
+};
+struct Family {
+  std::string name, help;
+  const char* type;
+  std::vector<Member> members;
+  bool last_not_idle = false;  // the synthesised gpu_last_not_idle_time family
+};
+
+const char* kBlockNames[] = {"umc", "gfx", "sdma", "mmhub", "xgmi"};
+
+std::vector<Family> build_families(bool profiling, bool extras) {
+  std::vector<Family> fams;
+  auto add = [&](uint16_t id) {
+    const FieldDef* f = field_def(id);
+    if (!f || !f->prom_type) return;
+    Family* fam = nullptr;
+    for (auto& x : fams)
+      if (x.name == f->prom_name) fam = &x;
+    if (!fam) {
+      fams.push_back(Family());
+      fam = &fams.back();
+      fam->name = f->prom_name;
+      fam->help = f->prom_help;
+      fam->type = f->prom_type == 2 ? "counter" : "gauge";
+    }
+    Member m;
+    m.field = id;
+    m.label = f->extra_label;
+    if (f->extra_label)
+      m.label_value = !strcmp(f->extra_label, "block") ? kBlockNames[f->extra_index] : strprintf("%d", f->extra_index);
+    fam->members.push_back(m);
+  };
+  for (uint16_t id : contract_fields()) {
+    add(id);
+    if (id == GM_FI_GFX_UTIL) {
+      // Synthesised per GPU: wall-clock second latched whenever utilisation is
+      // above 2 % or the GPU is seen for the first time
+      // (exporters/prometheus-dcgm/dcgm-exporter/dcgm-exporter:104-109,140).
+      Family f;
+      f.name = "dcgm_gpu_last_not_idle_time";
+      f.help = "Timestamp of last time GPU utilization was 2% or less.";
+      f.type = "gauge";
+      f.last_not_idle = true;
+      f.members.push_back(Member{GM_FI_GFX_UTIL, nullptr, ""});
+      fams.push_back(f);
+    }
+  }
+  if (profiling)
+    for (uint16_t id : profiling_fields()) add(id);
+  if (extras)
+    for (uint16_t id : extra_fields()) add(id);
+  return fams;
+}
+
+void append_escaped(std::string* out, const std::string& s) {
+  for (char c : s) {
+    if (c == '\\') *out += "\\\\";
+    else if (c == '"') *out += "\\\"";
+    else if (c == '\n') *out += "\\n";
+    else *out += c;
+  }
+}
+
+void append_value(std::string* out, const gm_value_t& v) {
+  char buf[48];
+  if (v.type == GM_FT_DOUBLE) {
+    if (std::isnan(v.v.dbl)) { *out += "NaN"; return; }
+    snprintf(buf, sizeof buf, "%.3f", v.v.dbl);
+  } else {
+    snprintf(buf, sizeof buf, "%lld", (long long)v.v.i64);
+  }
+  *out += buf;
+}
+
+}  // namespace
+
+Exporter::Exporter(Engine* engine, const ExporterConfig& cfg) : engine_(engine), cfg_(cfg) {
+  if (cfg_.interval_ms < 100) cfg_.interval_ms = 100;  // same floor as the reference's -d
+}
+
+Exporter::~Exporter() {
+  stop();
+  if (watching_) {
+    engine_->unwatch_fields(group_, fg_);
+    engine_->field_group_destroy(fg_);
+    engine_->group_destroy(group_);
+  }
+}
+
+gm_status_t Exporter::init() {
+  std::vector<uint32_t> supported;
+  gm_status_t st = engine_->supported_devices(&supported);
+  if (st != GM_ST_OK) return st;
+  gpus_.clear();
+  std::string sel = trim(cfg_.gpus);
+  if (sel.empty() || sel == "-1") {
+    gpus_ = supported;
+  } else {
+    for (auto& t : split(sel, ',')) {
+      std::string x = trim(t);
+      if (x.empty()) continue;
+      char* end = nullptr;
+      long v = strtol(x.c_str(), &end, 10);
+      if (*end || v < 0) return GM_ST_BADPARAM;
+      if (std::find(supported.begin(), supported.end(), (uint32_t)v) == supported.end()) return GM_ST_GPU_NOT_SUPPORTED;
+      if (std::find(gpus_.begin(), gpus_.end(), (uint32_t)v) == gpus_.end()) gpus_.push_back((uint32_t)v);
+    }
+    std::sort(gpus_.begin(), gpus_.end());
+  }
+  uuids_.clear();
+  bdfs_.clear();
+  for (uint32_t g : gpus_) {
+    gm_device_attributes_t a;
+    a.version = GM_DEVICE_ATTRIBUTES_VERSION;
+    st = engine_->device_attributes(g, &a);
+    if (st != GM_ST_OK) return st;
+    uuids_.push_back(a.uuid);
+    std::string bdf = a.pci_bdf;
+    for (auto& c : bdf) c = (char)tolower((unsigned char)c);
+    bdfs_.push_back(bdf);
+  }
+  fields_.clear();
+  for (auto& fam : build_families(cfg_.profiling, cfg_.amd_extras))
+    for (auto& m : fam.members)
+      if (std::find(fields_.begin(), fields_.end(), m.field) == fields_.end()) fields_.push_back(m.field);
+
+  static std::atomic<uint32_t> seq{0};
+  std::string tag = strprintf("gpumon-exporter-%d-%u", (int)getpid(), seq++);
+  st = engine_->group_create(tag, &group_);
+  if (st != GM_ST_OK) return st;
+  for (uint32_t g : gpus_)
+    if ((st = engine_->group_add(group_, g)) != GM_ST_OK) return st;
+  st = engine_->field_group_create(fields_, tag, &fg_);
+  if (st != GM_ST_OK) return st;
+  st = engine_->watch_fields(group_, fg_, cfg_.interval_ms * 1000, GM_DEFAULT_MAX_KEEP_AGE_S, 2);
+  if (st != GM_ST_OK) return st;
+  watching_ = true;
+  if (cfg_.self_metrics) engine_->introspect_toggle(true);
+  if (!cfg_.pod_map_path.empty() || !cfg_.kubelet_socket.empty()) refresh_pod_map();
+  return GM_ST_OK;
+}
+
+void Exporter::set_pod_map(const PodMap& m) {
+  std::lock_guard<std::mutex> l(mu_);
+  pod_map_ = m;
+}
+
+void Exporter::refresh_pod_map() {
+  PodMap m;
+  bool ok = false;
+  if (!cfg_.kubelet_socket.empty()) {
+    std::string err;
+    gm_status_t st = kubelet_list_pod_resources(cfg_.kubelet_socket, cfg_.resource_names, 10000, &m, &err);
+    ok = st == GM_ST_OK;
+    if (!ok) GM_LOGW("pod attribution: kubelet query failed: %s", err.c_str());
+  }
+  if (!ok && !cfg_.pod_map_path.empty()) {
+    std::string text;
+    if (read_file(cfg_.pod_map_path, &text)) {
+      if (!text.empty() && text[0] == '{') ok = parse_device_plugin_checkpoint(text, cfg_.resource_names, &m);
+      else { m = parse_pod_map_tsv(text); ok = true; }
+    }
+  }
+  pod_map_ok_ = ok ? 1 : 0;
+  last_pod_refresh_mono_ = monotonic_us();
+  if (ok) set_pod_map(m);  // on failure keep the last good map
+}
+
+void Exporter::render(std::string* out) {
+  int64_t t0 = monotonic_us();
+  static const std::vector<Family> fam_all[4] = {build_families(false, false), build_families(true, false),
+                                                 build_families(false, true), build_families(true, true)};
+  const std::vector<Family>& fams = fam_all[(cfg_.profiling ? 1 : 0) | (cfg_.amd_extras ? 2 : 0)];
+  const size_t nf = fields_.size(), ng = gpus_.size();
+  std::lock_guard<std::mutex> l(mu_);
+  scratch_.resize(nf * ng);
+  std::vector<bool> gpu_ok(ng, false);
+  for (size_t g = 0; g < ng; g++)
+    gpu_ok[g] = engine_->latest_values(gpus_[g], fields_.data(), (int)nf, &scratch_[g * nf]) == GM_ST_OK;
+  auto value_of = [&](size_t g, uint16_t field) -> const gm_value_t* {
+    for (size_t i = 0; i < nf; i++)
+      if (fields_[i] == field) return &scratch_[g * nf + i];
+    return nullptr;
+  };
+  int64_t now_s = now_us() / 1000000;
+
+  // Label blocks are fixed per GPU for one render.
+  std::vector<std::string> base(ng), podl(ng);
+  for (size_t g = 0; g < ng; g++) {
+    base[g] = strprintf("{gpu=\"%u\",uuid=\"", gpus_[g]);
+    append_escaped(&base[g], uuids_[g]);
+    base[g] += "\"";
+    const PodInfo* p = nullptr;
+    auto it = pod_map_.find(uuids_[g]);
+    if (it != pod_map_.end()) p = &it->second;
+    if (!p && (it = pod_map_.find(bdfs_[g])) != pod_map_.end()) p = &it->second;
+    static const char* prefixes[] = {"amdgpu", "gpu", "card", "nvidia"};
+    for (size_t k = 0; !p && k < sizeof prefixes / sizeof prefixes[0]; k++)
+      if ((it = pod_map_.find(strprintf("%s%u", prefixes[k], gpus_[g]))) != pod_map_.end()) p = &it->second;
+    if (p) {
+      podl[g] = ",pod_name=\"";
+      append_escaped(&podl[g], p->pod);
+      podl[g] += "\",pod_namespace=\"";
+      append_escaped(&podl[g], p->ns);
+      podl[g] += "\",container_name=\"";
+      append_escaped(&podl[g], p->container);
+      podl[g] += "\"";
+    }
+  }
+
+  out->clear();
+  out->reserve(ng * fams.size() * 96 + 4096);
+  auto emit_sample = [&](const Family& fam, const Member& m, size_t g) {
+    if (!gpu_ok[g]) return false;
+    const gm_value_t* v = value_of(g, m.field);
+    if (!v || v->status != GM_VS_OK) return false;  // blank values are omitted, like "N/A" in the reference
+    *out += fam.name;
+    *out += base[g];
+    if (m.label) {
+      *out += ",";
+      *out += m.label;
+      *out += "=\"";
+      *out += m.label_value;
+      *out += "\"";
+    }
+    *out += podl[g];
+    *out += "} ";
+    if (fam.last_not_idle) {
+      int64_t util = v->type == GM_FT_DOUBLE ? (int64_t)v->v.dbl : v->v.i64;
+      auto it = last_not_idle_.find(gpus_[g]);
+      if (it == last_not_idle_.end() || util > 2) last_not_idle_[gpus_[g]] = now_s;
+      *out += strprintf("%lld", (long long)last_not_idle_[gpus_[g]]);
+    } else {
+      append_value(out, *v);
+    }
+    *out += "\n";
+    return true;
+  };
+  auto emit_header = [&](const Family& fam) {
+    *out += "# HELP ";
+    *out += fam.name;
+    *out += " ";
+    *out += fam.help;
+    *out += "\n# TYPE ";
+    *out += fam.name;
+    *out += " ";
+    *out += fam.type;
+    *out += "\n";
+  };
+
+  if (!cfg_.legacy_layout) {
+    // Valid exposition format: HELP, TYPE, then every sample of the family.
+    for (auto& fam : fams) {
+      size_t mark = out->size();
+      emit_header(fam);
+      size_t after_header = out->size();
+      for (size_t g = 0; g < ng; g++)
+        for (auto& m : fam.members) emit_sample(fam, m, g);
+      if (out->size() == after_header) out->resize(mark);  // nothing to say: no orphan header
+    }
+  } else {
+    // GPU-major layout of the reference's awk program: headers accompany the
+    // first exported GPU only (dcgm-exporter:97-113).
+    for (size_t g = 0; g < ng; g++)
+      for (auto& fam : fams)
+        for (auto& m : fam.members) {
+          size_t mark = out->size();
+          if (g == 0) emit_header(fam);
+          size_t after_header = out->size();
+          if (!emit_sample(fam, m, g) && g == 0 && out->size() == after_header) out->resize(mark);
+        }
+  }
+  if (cfg_.self_metrics) render_self(out);
+  last_render_us_ = monotonic_us() - t0;
+}
+
+void Exporter::render_self(std::string* out) {
+  auto gauge = [&](const char* name, const char* help, double v, const char* type = "gauge") {
+    *out += strprintf("# HELP %s %s\n# TYPE %s %s\n%s %.6g\n", name, help, name, type, name, v);
+  };
+  gm_introspect_t in;
+  in.version = GM_INTROSPECT_VERSION;
+  if (engine_->introspect(&in) == GM_ST_OK) {
+    gauge("gpumon_engine_memory_kb", "Resident memory of the host engine (in KB).", (double)in.memory_kb);
+    gauge("gpumon_engine_cpu_percent", "CPU utilization of the host engine (in % of one core).", in.cpu_percent);
+    gauge("gpumon_engine_sample_cycle_seconds", "Wall time of the last sample cycle over all GPUs.", in.last_cycle_ms / 1e3);
+    gauge("gpumon_engine_sample_cycles_total", "Sample cycles completed.", (double)in.sample_cycles, "counter");
+    gauge("gpumon_engine_backend_errors_total", "Device-library calls that failed.", (double)in.backend_errors, "counter");
+  }
+  gauge("gpumon_exporter_render_duration_seconds", "Wall time of the previous text render.", (double)last_render_us_ / 1e6);
+  gauge("gpumon_exporter_sweeps_total", "File sweeps published.", (double)sweeps_, "counter");
+  gauge("gpumon_exporter_scrapes_total", "HTTP scrapes served.", (double)scrapes_, "counter");
+  gauge("gpumon_exporter_publish_errors_total", "File publishes that failed.", (double)publish_errors_, "counter");
+  if (pod_map_ok_ >= 0) gauge("gpumon_exporter_pod_map_up", "1 if the last pod-resources query succeeded.", (double)pod_map_ok_);
+}
+
+gm_status_t Exporter::publish() {
+  std::string text;
+  render(&text);
+  if (!cfg_.output_path.empty()) {
+    size_t slash = cfg_.output_path.rfind('/');
+    if (slash != std::string::npos && slash > 0) mkdir(cfg_.output_path.substr(0, slash).c_str(), 0755);
+    if (!write_file_atomic(cfg_.output_path, text.data(), text.size())) {
+      publish_errors_++;
+      GM_LOGE("exporter: cannot publish %s: %s", cfg_.output_path.c_str(), strerror(errno));
+      return GM_ST_GENERIC_ERROR;
+    }
+  }
+  sweeps_++;
+  last_sweep_us_ = now_us();
+  return GM_ST_OK;
+}
+
+gm_status_t Exporter::sweep() {
+  gm_status_t st = engine_->update_all(true);
+  if (st != GM_ST_OK) return st;
+  return publish();
+}
+
+void Exporter::handle_http(const HttpRequest& req, HttpResponse* resp) {
+  if (req.path == "/metrics" || req.path == "/gpu/metrics") {
+    scrapes_++;
+    render(&resp->body);
+    resp->content_type = "text/plain; version=0.0.4; charset=utf-8";
+    return;
+  }
+  if (req.path == "/healthz") {
+    // Live while sweeps keep coming (the reference's pod exporter dies after
+    // 10 minutes without a new file: src/watchers.go:56-59).
+    int64_t age_us = now_us() - last_sweep_us_.load();
+    bool ok = !running_ || last_sweep_us_ == 0 || age_us < std::max<int64_t>(600000000, cfg_.interval_ms * 3000);
+    resp->status = ok ? 200 : 503;
+    resp->body = ok ? "ok\n" : "stale\n";
+    return;
+  }
+  if (cfg_.rest_api && handle_rest(engine_, req, resp)) return;
+  resp->status = 404;
+  resp->body = "404 page not found\n";
+}
+
+void Exporter::loop() {
+  // The first sweep forces a sample, which also anchors the sampler's drift-free
+  // schedule; later iterations only render what the sampler has cached.  Both
+  // schedules run off the monotonic clock, so publishing a fixed margin after
+  // every sampler tick keeps the file one tick fresh without sampling twice.
+  int64_t anchor = monotonic_us();
+  gm_status_t st = sweep();
+  if (st != GM_ST_OK) GM_LOGW("exporter sweep failed: %s", status_string(st));
+  const int64_t interval = cfg_.interval_ms * 1000;
+  int64_t next = anchor + interval + std::min<int64_t>(interval / 10, 100000);
+  while (running_) {
+    {
+      std::unique_lock<std::mutex> l(wake_mu_);
+      int64_t now = monotonic_us();
+      if (next > now) wake_cv_.wait_for(l, std::chrono::microseconds(next - now), [&] { return !running_.load(); });
+    }
+    if (!running_) break;
+    if ((st = publish()) != GM_ST_OK) GM_LOGW("exporter publish failed: %s", status_string(st));
+    // Pod map on its own slower schedule instead of one kubelet dial per sweep
+    // (the reference dials once a second: src/watchers.go:41).
+    if ((!cfg_.kubelet_socket.empty() || !cfg_.pod_map_path.empty()) &&
+        monotonic_us() - last_pod_refresh_mono_ >= std::min<int64_t>(10000000, std::max<int64_t>(interval, 1000000)))
+      refresh_pod_map();
+    next += interval;
+    int64_t now = monotonic_us();
+    if (next <= now) next = now + interval;
+  }
+}
+
+gm_status_t Exporter::start() {
+  if (running_.exchange(true)) return GM_ST_OK;
+  if (!cfg_.listen.empty()) {
+    if (!http_.start(cfg_.listen, [this](const HttpRequest& rq, HttpResponse* rs) { handle_http(rq, rs); })) {
+      running_ = false;
+      return GM_ST_GENERIC_ERROR;
+    }
+  }
+  th_ = std::thread([this] { loop(); });
+  return GM_ST_OK;
+}
+
+void Exporter::stop() {
+  if (!running_.exchange(false)) return;
+  wake_cv_.notify_all();
+  if (th_.joinable()) th_.join();
+  http_.stop();
+}
+
+}  // namespace gpumon

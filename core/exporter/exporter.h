@@ -1,0 +1,105 @@
+// Native Prometheus exporter: sampler cache -> text renderer -> atomic file
+// sink and/or in-process HTTP.  One process, no forks, no text re-parsing; it
+// replaces the `dcgmi dmon | gawk` pipeline of the reference
+// (exporters/prometheus-dcgm/dcgm-exporter/dcgm-exporter:85-194) and folds in
+// the pod-attribution rewrite of its companion exporter
+// (exporters/prometheus-dcgm/k8s/pod-gpu-metrics-exporter/src/device_pod.go:57-113).
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../engine/engine.h"
+#include "http.h"
+
+namespace gpumon {
+
+struct PodInfo {
+  std::string pod, ns, container;
+};
+using PodMap = std::map<std::string, PodInfo>;  // device id -> pod
+
+// TSV: "<device-id>\t<pod>\t<namespace>\t<container>\n".
+PodMap parse_pod_map_tsv(const std::string& tsv);
+std::string pod_map_to_tsv(const PodMap& m);
+// Kubelet device-plugin checkpoint (JSON) fallback: device id -> pod UID / container.
+bool parse_device_plugin_checkpoint(const std::string& json, const std::string& resource_names, PodMap* out);
+// Appends pod labels to the samples of an existing exposition text.
+std::string relabel_text(const std::string& text, const PodMap& m, const std::string& index_prefix);
+// Kubelet PodResources List() over a unix socket (gRPC, hand-rolled HTTP/2).
+gm_status_t kubelet_list_pod_resources(const std::string& socket_path, const std::string& resource_names,
+                                       int timeout_ms, PodMap* out, std::string* error);
+
+struct ExporterConfig {
+  bool profiling = false;
+  bool amd_extras = false;
+  bool self_metrics = false;
+  bool rest_api = false;
+  bool legacy_layout = false;
+  int64_t interval_ms = 1000;
+  std::string gpus;  // "" / "-1" = all
+  std::string output_path;
+  std::string listen;
+  std::string kubelet_socket;
+  std::string resource_names = "amd.com/gpu";
+  std::string pod_map_path;
+};
+
+class Exporter {
+ public:
+  Exporter(Engine* engine, const ExporterConfig& cfg);
+  ~Exporter();
+  gm_status_t init();
+  void render(std::string* out);  // from the cache; never samples
+  gm_status_t publish();          // render + publish file
+  gm_status_t sweep();            // force-sample, then publish
+  gm_status_t start();
+  void stop();
+  int http_port() const { return http_.port(); }
+  void set_pod_map(const PodMap& m);
+  const std::vector<uint32_t>& gpus() const { return gpus_; }
+
+ private:
+  void loop();
+  void refresh_pod_map();
+  void handle_http(const HttpRequest& req, HttpResponse* resp);
+  void render_self(std::string* out);
+
+  Engine* engine_;
+  ExporterConfig cfg_;
+  std::vector<uint32_t> gpus_;
+  std::vector<std::string> uuids_, bdfs_;
+  std::vector<uint16_t> fields_;  // every field id fetched per GPU
+  gm_group_t group_ = 0;
+  gm_field_group_t fg_ = 0;
+  bool watching_ = false;
+
+  std::mutex mu_;  // last_not_idle_, pod_map_, cached text
+  std::map<uint32_t, int64_t> last_not_idle_;
+  PodMap pod_map_;
+  std::string cached_;  // last published text (served over HTTP between sweeps)
+  std::vector<gm_value_t> scratch_;
+
+  std::atomic<bool> running_{false};
+  std::thread th_;
+  std::mutex wake_mu_;
+  std::condition_variable wake_cv_;
+  HttpServer http_;
+
+  std::atomic<uint64_t> sweeps_{0}, scrapes_{0}, publish_errors_{0};
+  std::atomic<int64_t> last_render_us_{0}, last_sweep_us_{0}, last_pod_refresh_mono_{0};
+  std::atomic<int> pod_map_ok_{-1};
+};
+
+// REST routes of the reference's sample server (bindings/go/samples/dcgm/restApi/
+// server.go:40-71) under /dcgm/... with /gpumon/... aliases.  Returns false
+// when the path is not a REST route.
+bool handle_rest(Engine* engine, const HttpRequest& req, HttpResponse* resp);
+
+}  // namespace gpumon
