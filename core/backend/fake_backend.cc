@@ -53,6 +53,7 @@ class FakeBackend : public Backend {
       else if (k == "load") default_load_ = atof(v.c_str());
       else if (k == "unsupported_gpu") unsupported_gpu_ = atoi(v.c_str());
       else if (k == "sample_cost_us") sample_cost_us_ = atoi(v.c_str());
+      else if (k == "steady") steady_ = atoi(v.c_str()) != 0;  // telemetry independent of the sample count
     }
     if (ngpus_ > GM_MAX_GPUS) ngpus_ = GM_MAX_GPUS;
   }
@@ -136,7 +137,8 @@ class FakeBackend : public Backend {
     g.n++;
     const double load = g.load;
     const int64_t n = (int64_t)g.n;
-    const int64_t wobble = (int64_t)((n + gpu) % 3);
+    const int64_t wobble = steady_ ? 0 : (int64_t)((n + gpu) % 3);
+    const int64_t adv = steady_ ? (g.n == 1 ? 1 : 0) : 1;  // counters advance once, then hold, in steady mode
 
     if (ok & SRC_METRICS) {
       int64_t util = (int64_t)load;
@@ -155,8 +157,8 @@ class FakeBackend : public Backend {
       for (int i = 0; i < GM_MAX_HBM_STACKS; i++) out->set_i(GM_FI_HBM_STACK_TEMP_0 + i, hot - 3 - (i & 1));
       double power = 140.0 + gpu + load * 12.0 + (double)wobble;
       out->set_d(GM_FI_POWER_USAGE, power);
-      g.pcie_tx_kb += 1200 + (int64_t)(load * 4000);
-      g.pcie_rx_kb += 900 + (int64_t)(load * 6000);
+      g.pcie_tx_kb += adv * (1200 + (int64_t)(load * 4000));
+      g.pcie_rx_kb += adv * (900 + (int64_t)(load * 6000));
       out->set_i(GM_FI_PCIE_TX_KB, g.pcie_tx_kb);
       out->set_i(GM_FI_PCIE_RX_KB, g.pcie_rx_kb);
       out->set_i(GM_FI_PCIE_REPLAY_COUNTER, g.pcie_replay);
@@ -182,8 +184,8 @@ class FakeBackend : public Backend {
           continue;
         }
         if (g.link_up[i]) {
-          g.xgmi_rx[i] += (int64_t)(load * 150000) + 10;
-          g.xgmi_tx[i] += (int64_t)(load * 150000) + 12;
+          g.xgmi_rx[i] += adv * ((int64_t)(load * 150000) + 10);
+          g.xgmi_tx[i] += adv * ((int64_t)(load * 150000) + 12);
           up++;
         } else {
           down++;
@@ -233,7 +235,7 @@ class FakeBackend : public Backend {
       out->set_i(GM_FI_BAD_PAGES_PENDING, g.bad_pending);
     }
     if (ok & SRC_ENERGY) {
-      g.energy_mj += (int64_t)((140.0 + gpu + load * 12.0) * 1000.0);
+      g.energy_mj += adv * (int64_t)((140.0 + gpu + load * 12.0) * 1000.0);
       out->set_i(GM_FI_TOTAL_ENERGY, g.energy_mj);
     }
     if (ok & SRC_PERF) {
@@ -442,7 +444,7 @@ class FakeBackend : public Backend {
 
  private:
   uint32_t ngpus_ = 8, seed_ = 1;
-  bool fail_init_ = false, events_supported_ = true, topology_unsupported_ = false;
+  bool fail_init_ = false, events_supported_ = true, topology_unsupported_ = false, steady_ = false;
   double default_load_ = 0;
   int unsupported_gpu_ = -1;
   int sample_cost_us_ = 0;

@@ -1,0 +1,156 @@
+/*
+ * gpumon_diag.h — C ABI of the active diagnostics (libgpumon_diag.so).
+ *
+ * Hand-written CDNA4 (gfx950) HIP kernels in the role of DCGM's diagnostic
+ * plugins, which the reference depends on being installed but never wraps:
+ *   - HBM stream bandwidth   (copy / scale / add / triad / read / write)
+ *   - memtest pattern sweep  (write + verify over most of the 288 GB HBM3E)
+ *   - MFMA stress            (register-resident matrix-pipe peak, and a
+ *                             LDS-tiled bf16 / fp8 GEMM with an SDC checksum)
+ * Every entry point is synchronous, selects `device` itself and returns 0 or a
+ * negative gmd error; pointer-taking variants run on caller-owned device
+ * memory so tests can check numerics against an independent reference.
+ */
+#ifndef GPUMON_DIAG_H_
+#define GPUMON_DIAG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMD_API __attribute__((visibility("default")))
+
+enum {
+  GMD_OK = 0,
+  GMD_ERR_BADPARAM = -1,
+  GMD_ERR_HIP = -2,      /* a HIP call failed; see gmd_last_error() */
+  GMD_ERR_NO_DEVICE = -3,
+  GMD_ERR_NOMEM = -4,
+  GMD_ERR_VERIFY = -5    /* the kernel ran but its result is wrong */
+};
+
+GMD_API const char* gmd_last_error(void);
+GMD_API int gmd_device_count(void);
+typedef struct {
+  char name[128];
+  char gcn_arch[64];
+  uint64_t total_mem, free_mem;
+  int compute_units, clock_mhz, mem_clock_mhz, l2_bytes, lds_per_cu;
+  char pci_bdf[32];
+} gmd_device_info_t;
+GMD_API int gmd_device_info(int device, gmd_device_info_t* out);
+
+/* ------------------------------------------------------------ HBM stream -- */
+typedef enum {
+  GMD_STREAM_COPY = 0,  /* c = a            2 x bytes */
+  GMD_STREAM_SCALE = 1, /* b = s * c        2 x bytes */
+  GMD_STREAM_ADD = 2,   /* c = a + b        3 x bytes */
+  GMD_STREAM_TRIAD = 3, /* a = b + s * c    3 x bytes */
+  GMD_STREAM_READ = 4,  /* sum(a)           1 x bytes */
+  GMD_STREAM_WRITE = 5, /* a = s            1 x bytes */
+  GMD_STREAM_KERNELS = 6
+} gmd_stream_kernel_t;
+
+typedef struct {
+  double tbps_best;     /* 1e12 bytes per second, best iteration */
+  double tbps_median;
+  double ms_best;
+  uint64_t bytes_per_iter; /* bytes read + written by one launch */
+  int32_t verified;        /* 1 = sampled results checked and correct */
+  int32_t iters;
+} gmd_stream_result_t;
+
+/* Allocates its own buffers of `bytes_per_buffer` each (use >= 1 GiB: the
+ * 256 MiB Infinity Cache must not hold the working set). */
+GMD_API int gmd_hbm_stream(int device, int kernel, uint64_t bytes_per_buffer, int iters, int nontemporal,
+                           gmd_stream_result_t* out);
+/* One launch on caller buffers (float elements); for numerics tests. */
+GMD_API int gmd_hbm_stream_launch(int kernel, void* a, void* b, void* c, float scalar, uint64_t n_floats,
+                                  int nontemporal, void* hip_stream);
+
+/* --------------------------------------------------------------- memtest -- */
+#define GMD_PAT_WALKING_ONES (1u << 0)
+#define GMD_PAT_WALKING_ZEROS (1u << 1)
+#define GMD_PAT_ADDRESS (1u << 2)      /* every word holds its own index */
+#define GMD_PAT_CHECKERBOARD (1u << 3) /* 0xAAAA... */
+#define GMD_PAT_INV_CHECKERBOARD (1u << 4)
+#define GMD_PAT_RANDOM (1u << 5)       /* counter-based hash of (index, seed) */
+#define GMD_PAT_MODULO_20 (1u << 6)    /* one word in 20 differs */
+#define GMD_PAT_ALL 0x7fu
+#define GMD_MEMTEST_LOG 32
+
+typedef struct {
+  uint64_t byte_offset; /* offset inside the tested region */
+  uint64_t expected, actual;
+  uint32_t pattern; /* one GMD_PAT_* bit */
+  uint32_t chunk;
+} gmd_memtest_error_t;
+
+typedef struct {
+  uint64_t bytes_tested;   /* size of the region under test */
+  uint64_t bytes_requested;
+  uint64_t errors;         /* mismatching 64-bit words, all patterns */
+  uint32_t patterns_run;
+  uint32_t chunks;
+  double write_tbps, verify_tbps; /* mean over patterns */
+  double seconds;
+  uint32_t logged;
+  gmd_memtest_error_t log[GMD_MEMTEST_LOG];
+} gmd_memtest_result_t;
+
+typedef void (*gmd_progress_cb)(double fraction, const char* what, void* user);
+
+typedef struct {
+  uint64_t bytes;        /* region size; 0 = fraction of the free HBM */
+  double fraction;       /* used when bytes == 0; default 0.90 */
+  uint64_t chunk_bytes;  /* allocation granule; default 2 GiB */
+  uint32_t patterns;     /* mask of GMD_PAT_*; 0 = all */
+  uint32_t passes;       /* repeats of the whole sweep; default 1 */
+  uint64_t seed;
+  /* Fault injection for tests: XOR `inject_xor` into the 64-bit word at
+   * `inject_offset` between the write and the verify pass of every pattern.
+   * inject_xor == 0 disables it. */
+  uint64_t inject_offset;
+  uint64_t inject_xor;
+  gmd_progress_cb progress;
+  void* progress_user;
+} gmd_memtest_config_t;
+
+GMD_API int gmd_memtest(int device, const gmd_memtest_config_t* cfg, gmd_memtest_result_t* out);
+/* Single passes on a caller buffer (n_words 64-bit words, 16-byte aligned, even count). */
+GMD_API int gmd_memtest_fill(void* buf, uint64_t n_words, uint64_t base_word, uint32_t pattern, uint64_t seed,
+                             void* hip_stream);
+GMD_API int gmd_memtest_verify(const void* buf, uint64_t n_words, uint64_t base_word, uint32_t pattern, uint64_t seed,
+                               uint64_t* errors_out, gmd_memtest_error_t* log, uint32_t* logged, void* hip_stream);
+
+/* ----------------------------------------------------------- MFMA stress -- */
+typedef enum { GMD_DT_BF16 = 0, GMD_DT_FP8 = 1, GMD_DT_F32 = 2, GMD_DT_MXFP8 = 3 } gmd_dtype_t;
+
+typedef struct {
+  double tflops;       /* dense, 2*M*N*K per GEMM (or MFMA flops for the pipe test) */
+  double tflops_best;  /* best single launch */
+  double seconds;
+  uint64_t launches;
+  double clock_mhz_est; /* shader clock held during the run, from s_memtime / s_memrealtime; 0 = not measured */
+  int32_t verified;     /* 1 = checksum / reference comparison passed, 0 = not checked, -1 = failed */
+  uint64_t sdc_mismatches; /* launches whose checksum differed from the first launch */
+  double max_rel_err;
+} gmd_mfma_result_t;
+
+/* Matrix-pipe peak: MFMAs on register-resident operands, no memory traffic. */
+GMD_API int gmd_mfma_peak(int device, int dtype, double seconds, gmd_mfma_result_t* out);
+/* GEMM stress: C[M,N] = A[M,K] * B[N,K]^T on random data for `seconds` (>= 1 launch);
+ * every launch's output checksum is compared with the first one (silent-data-corruption check). */
+GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, int verify,
+                            gmd_mfma_result_t* out);
+/* One GEMM on caller memory.  A: [M,K] row-major, B: [N,K] row-major (i.e. B^T), C: [M,N] row-major.
+ * bf16: A,B bf16, C bf16.  fp8: A,B OCP e4m3, C bf16.  M,N multiples of 256; K multiple of 64 (bf16) / 128 (fp8). */
+GMD_API int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,285 @@
+// HBM memtest for MI355X: pattern sweep over (almost) all of the 288 GB HBM3E.
+//
+// For each pattern the whole region is written, then read back and compared
+// against the value recomputed from the word index — no reference copy, so the
+// test covers twice the memory a copy-compare test could.  Patterns follow the
+// classic memory-test repertoire (walking ones / zeros, address-in-address,
+// checkerboard and its inverse, a counter-based pseudo-random fill, modulo-20).
+// Both passes move 16 bytes per lane per access (two 64-bit words) from a
+// grid-stride loop sized for 256 CUs; mismatches are counted with one atomic
+// per mismatching lane (rare) and the first few are logged with offset,
+// expected and actual value so a failing HBM stack / channel can be located.
+//
+// The region is allocated in chunks (default 2 GiB) so a fragmented heap still
+// yields high coverage; allocation stops at the first failure and the achieved
+// coverage is reported.
+#include <chrono>
+
+#include "diag_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// Value of 64-bit word `w` (global index inside the tested region).
+__host__ __device__ __forceinline__ uint64_t expected_word(uint32_t pattern, uint64_t w, uint64_t seed) {
+  switch (pattern) {
+    case GMD_PAT_WALKING_ONES: return 1ull << ((w + seed) & 63);
+    case GMD_PAT_WALKING_ZEROS: return ~(1ull << ((w + seed) & 63));
+    case GMD_PAT_ADDRESS: return w * 8;  // its own byte offset
+    case GMD_PAT_CHECKERBOARD: return (w & 1) ? 0x5555555555555555ull : 0xAAAAAAAAAAAAAAAAull;
+    case GMD_PAT_INV_CHECKERBOARD: return (w & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+    case GMD_PAT_RANDOM: return splitmix64(w ^ (seed * 0xD1342543DE82EF95ull));
+    case GMD_PAT_MODULO_20: return (w % 20 == seed % 20) ? 0xFFFFFFFFFFFFFFFFull : 0ull;
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(kBlock) void fill_kernel(u64x2* __restrict__ buf, uint64_t n2, uint64_t base_word,
+                                                      uint32_t pattern, uint64_t seed) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+    const uint64_t w = base_word + 2 * i;
+    u64x2 v = {expected_word(pattern, w, seed), expected_word(pattern, w + 1, seed)};
+    buf[i] = v;  // plain stores: the pure-store stream measures faster without the nt hint
+  }
+}
+
+struct VerifyOut {
+  unsigned long long errors;
+  unsigned int logged;
+  unsigned int pad;
+  gmd_memtest_error_t log[GMD_MEMTEST_LOG];
+};
+
+__device__ __forceinline__ void report(VerifyOut* out, uint64_t word, uint64_t expect, uint64_t got, uint32_t pattern) {
+  atomicAdd(&out->errors, 1ull);
+  unsigned slot = atomicAdd(&out->logged, 1u);
+  if (slot < GMD_MEMTEST_LOG) {
+    out->log[slot].byte_offset = word * 8;
+    out->log[slot].expected = expect;
+    out->log[slot].actual = got;
+    out->log[slot].pattern = pattern;
+    out->log[slot].chunk = 0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void verify_kernel(const u64x2* __restrict__ buf, uint64_t n2, uint64_t base_word,
+                                                        uint32_t pattern, uint64_t seed, VerifyOut* out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + (kUnroll - 1) * stride < n2; i += kUnroll * stride) {
+    u64x2 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) v[u] = __builtin_nontemporal_load(buf + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+      const uint64_t w = base_word + 2 * (i + u * stride);
+      const uint64_t e0 = expected_word(pattern, w, seed), e1 = expected_word(pattern, w + 1, seed);
+      if (v[u].x != e0) report(out, w, e0, v[u].x, pattern);
+      if (v[u].y != e1) report(out, w + 1, e1, v[u].y, pattern);
+    }
+  }
+  for (; i < n2; i += stride) {
+    u64x2 v = __builtin_nontemporal_load(buf + i);
+    const uint64_t w = base_word + 2 * i;
+    const uint64_t e0 = expected_word(pattern, w, seed), e1 = expected_word(pattern, w + 1, seed);
+    if (v.x != e0) report(out, w, e0, v.x, pattern);
+    if (v.y != e1) report(out, w + 1, e1, v.y, pattern);
+  }
+}
+
+__global__ void xor_word_kernel(unsigned long long* p, unsigned long long mask) { *p ^= mask; }
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+bool valid_pattern(uint32_t p) { return p && !(p & (p - 1)) && (p & GMD_PAT_ALL); }
+
+}  // namespace
+
+extern "C" {
+
+int gmd_memtest_fill(void* buf, uint64_t n_words, uint64_t base_word, uint32_t pattern, uint64_t seed, void* hip_stream) {
+  if (!buf || !n_words || (n_words & 1) || ((uintptr_t)buf & 15) || !valid_pattern(pattern)) return GMD_ERR_BADPARAM;
+  const uint64_t n2 = n_words / 2;
+  fill_kernel<<<gmd::stream_grid(n2, kBlock, kUnroll), kBlock, 0, (hipStream_t)hip_stream>>>((u64x2*)buf, n2, base_word,
+                                                                                          pattern, seed);
+  GMD_HIP(hipGetLastError());
+  return GMD_OK;
+}
+
+int gmd_memtest_verify(const void* buf, uint64_t n_words, uint64_t base_word, uint32_t pattern, uint64_t seed,
+                       uint64_t* errors_out, gmd_memtest_error_t* log, uint32_t* logged, void* hip_stream) {
+  if (!buf || !n_words || (n_words & 1) || ((uintptr_t)buf & 15) || !valid_pattern(pattern) || !errors_out)
+    return GMD_ERR_BADPARAM;
+  hipStream_t st = (hipStream_t)hip_stream;
+  VerifyOut* d = nullptr;
+  GMD_HIP(hipMalloc((void**)&d, sizeof(VerifyOut)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(VerifyOut), st);
+  const uint64_t n2 = n_words / 2;
+  if (e == hipSuccess) {
+    verify_kernel<<<gmd::stream_grid(n2, kBlock, kUnroll), kBlock, 0, st>>>((const u64x2*)buf, n2, base_word, pattern,
+                                                                           seed, d);
+    e = hipGetLastError();
+  }
+  VerifyOut h;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  if (e != hipSuccess) {
+    gmd::set_error("memtest verify failed: %s", hipGetErrorString(e));
+    return GMD_ERR_HIP;
+  }
+  *errors_out = h.errors;
+  uint32_t n = h.logged < GMD_MEMTEST_LOG ? h.logged : GMD_MEMTEST_LOG;
+  if (logged) *logged = n;
+  if (log) memcpy(log, h.log, n * sizeof(gmd_memtest_error_t));
+  return GMD_OK;
+}
+
+int gmd_memtest(int device, const gmd_memtest_config_t* cfg_in, gmd_memtest_result_t* out) {
+  if (!out) return GMD_ERR_BADPARAM;
+  memset(out, 0, sizeof *out);
+  gmd_memtest_config_t cfg;
+  memset(&cfg, 0, sizeof cfg);
+  if (cfg_in) cfg = *cfg_in;
+  if (cfg.fraction <= 0 || cfg.fraction > 0.98) cfg.fraction = 0.90;
+  if (!cfg.chunk_bytes) cfg.chunk_bytes = 2ull << 30;
+  cfg.chunk_bytes &= ~(uint64_t)4095;
+  if (cfg.chunk_bytes < 4096) return GMD_ERR_BADPARAM;
+  if (!cfg.patterns) cfg.patterns = GMD_PAT_ALL;
+  if (!cfg.passes) cfg.passes = 1;
+  GMD_HIP(hipSetDevice(device));
+  size_t free_b = 0, total_b = 0;
+  GMD_HIP(hipMemGetInfo(&free_b, &total_b));
+  uint64_t want = cfg.bytes ? cfg.bytes : (uint64_t)((double)free_b * cfg.fraction);
+  want &= ~(uint64_t)4095;
+  if (want < 4096) return GMD_ERR_BADPARAM;
+  out->bytes_requested = want;
+
+  struct Chunk {
+    void* p;
+    uint64_t bytes, base_word;
+  };
+  std::vector<Chunk> chunks;
+  uint64_t got = 0;
+  while (got < want) {
+    uint64_t sz = std::min<uint64_t>(cfg.chunk_bytes, want - got);
+    void* p = nullptr;
+    if (hipMalloc(&p, sz) != hipSuccess) {
+      (void)hipGetLastError();  // fragmentation or a neighbour's allocation: test what we have
+      break;
+    }
+    chunks.push_back({p, sz, got / 8});
+    got += sz;
+  }
+  auto cleanup = [&]() {
+    for (auto& c : chunks) (void)hipFree(c.p);
+  };
+  if (chunks.empty()) {
+    gmd::set_error("memtest: could not allocate any device memory (%llu bytes wanted)", (unsigned long long)want);
+    return GMD_ERR_NOMEM;
+  }
+  out->bytes_tested = got;
+  out->chunks = (uint32_t)chunks.size();
+
+  VerifyOut* d_out = nullptr;
+  if (hipMalloc((void**)&d_out, sizeof(VerifyOut)) != hipSuccess) {
+    cleanup();
+    gmd::set_error("memtest: out of memory for the result block");
+    return GMD_ERR_NOMEM;
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const double t_start = now_s();
+  double write_tbps_sum = 0, verify_tbps_sum = 0;
+  int npat = 0;
+  for (uint32_t b = 0; b < 7; b++)
+    if (cfg.patterns & (1u << b)) npat++;
+  const int total_steps = npat * (int)cfg.passes * 2;
+  int step = 0;
+  hipError_t err = hipSuccess;
+  for (uint32_t pass = 0; pass < cfg.passes && err == hipSuccess; pass++) {
+    for (uint32_t b = 0; b < 7 && err == hipSuccess; b++) {
+      const uint32_t pat = 1u << b;
+      if (!(cfg.patterns & pat)) continue;
+      const uint64_t seed = cfg.seed + pass * 7919 + b;
+      // ---- write pass
+      float ms = 0;
+      (void)hipEventRecord(e0, 0);
+      for (auto& c : chunks) {
+        const uint64_t n2 = c.bytes / 16;
+        fill_kernel<<<gmd::stream_grid(n2, kBlock, kUnroll), kBlock>>>((u64x2*)c.p, n2, c.base_word, pat, seed);
+      }
+      (void)hipEventRecord(e1, 0);
+      err = hipEventSynchronize(e1);
+      if (err != hipSuccess) break;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      write_tbps_sum += (double)got / (ms * 1e-3) / 1e12;
+      if (cfg.progress) cfg.progress((double)++step / total_steps, "write", cfg.progress_user);
+      // ---- optional fault injection
+      if (cfg.inject_xor && cfg.inject_offset / 8 < got / 8) {
+        const uint64_t word = cfg.inject_offset / 8;
+        for (auto& c : chunks)
+          if (word >= c.base_word && word < c.base_word + c.bytes / 8)
+            xor_word_kernel<<<1, 1>>>((unsigned long long*)c.p + (word - c.base_word), cfg.inject_xor);
+      }
+      // ---- verify pass
+      err = hipMemset(d_out, 0, sizeof(VerifyOut));
+      if (err != hipSuccess) break;
+      (void)hipEventRecord(e0, 0);
+      for (auto& c : chunks) {
+        const uint64_t n2 = c.bytes / 16;
+        verify_kernel<<<gmd::stream_grid(n2, kBlock, kUnroll), kBlock>>>((const u64x2*)c.p, n2, c.base_word, pat, seed,
+                                                                       d_out);
+      }
+      (void)hipEventRecord(e1, 0);
+      err = hipEventSynchronize(e1);
+      if (err != hipSuccess) break;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      verify_tbps_sum += (double)got / (ms * 1e-3) / 1e12;
+      VerifyOut h;
+      err = hipMemcpy(&h, d_out, sizeof h, hipMemcpyDeviceToHost);
+      if (err != hipSuccess) break;
+      out->errors += h.errors;
+      for (uint32_t i = 0; i < h.logged && i < GMD_MEMTEST_LOG && out->logged < GMD_MEMTEST_LOG; i++) {
+        gmd_memtest_error_t e = h.log[i];
+        for (size_t ci = 0; ci < chunks.size(); ci++)
+          if (e.byte_offset / 8 >= chunks[ci].base_word && e.byte_offset / 8 < chunks[ci].base_word + chunks[ci].bytes / 8)
+            e.chunk = (uint32_t)ci;
+        out->log[out->logged++] = e;
+      }
+      out->patterns_run++;
+      if (cfg.progress) cfg.progress((double)++step / total_steps, "verify", cfg.progress_user);
+    }
+  }
+  if (err == hipSuccess) err = hipGetLastError();
+  out->seconds = now_s() - t_start;
+  if (out->patterns_run) {
+    out->write_tbps = write_tbps_sum / out->patterns_run;
+    out->verify_tbps = verify_tbps_sum / out->patterns_run;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d_out);
+  cleanup();
+  if (err != hipSuccess) {
+    gmd::set_error("memtest failed: %s", hipGetErrorString(err));
+    return GMD_ERR_HIP;
+  }
+  return GMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,498 @@
+// MFMA targeted-stress diagnostics for MI355X (gfx950).
+//
+// (1) Matrix-pipe peak: every wave issues back-to-back MFMAs on register
+//     operands (no memory traffic) — the rate the matrix cores sustain at the
+//     clock the chip holds under that load.  bf16, fp8 (same rate as bf16),
+//     block-scaled MX-fp8 (K=128, 2x bf16 per clock) and f32-input forms.
+//
+// (2) GEMM stress: C[M,N] = A[M,K] * B[N,K]^T, 256x256 output tile per
+//     512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave, 32
+//     accumulators of mfma_f32_16x16x32), K-step of 128 bytes per row
+//     (64 bf16 / 128 fp8), operands staged HBM -> LDS by direct 16-byte
+//     LDS-DMA (global_load_lds) into two 64 KiB buffers and read back with
+//     ds_read_b128.
+//
+//     LDS image (both operands): 8-row x 128-byte pieces of 1 KiB — exactly
+//     what one LDS-DMA wave-instruction writes, so every instruction fetches
+//     eight whole 128-byte lines — with the 16-byte chunks of each row
+//     XOR-permuted:  chunk' = chunk ^ f(row & 7).  ds_read_b128 is serviced in
+//     four 16-lane groups and each group of an MFMA fragment read touches all
+//     16 rows once with two chunk values, so f is chosen to make the 16 slots
+//     of every group distinct: f = 2*((row&7)>>1) for bf16 (chunk pairs {c,c^1}),
+//     f = ((row&7)>>1 & 1) | ((row&7)>>2)<<2 for MX-fp8 (pairs {c,c^2}).
+//     Conflict-free reads, fully coalesced fetches, linear DMA destination;
+//     the permutation lives in the per-lane SOURCE address and in the read
+//     address, never in the DMA destination.
+//
+//     The MFMA takes the B fragment as its first operand and the A fragment as
+//     its second, which transposes the accumulator tile: each lane ends up with
+//     four consecutive N elements of one C row and stores them as one 8-byte
+//     word instead of four 2-byte scatters.
+//
+//     Workgroup ids are remapped so the tiles one XCD works on are contiguous
+//     (its private L2 then holds a few A row-panels and the B column panels it
+//     re-reads) with the bijective form that is valid for any grid size.
+#include <hip/hip_bf16.h>
+
+#include <chrono>
+#include <cmath>
+
+#include "diag_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef long i64x1;
+
+constexpr int BM = 256, BN = 256, BKB = 128;  // K-step in BYTES per row
+constexpr int kThreads = 512;
+constexpr int kTileBytes = BM * BKB;           // 32 KiB per operand per buffer
+constexpr int kBufBytes = 2 * kTileBytes;      // A + B
+constexpr int kLdsBytes = 2 * kBufBytes;       // double buffered: 128 KiB
+
+template <int DT>
+__device__ __forceinline__ int chunk_swizzle(int row_in_piece) {
+  const int q = row_in_piece >> 1;  // 0..3
+  if constexpr (DT == GMD_DT_BF16) return q << 1;
+  else return (q & 1) | ((q >> 1) << 2);
+}
+
+// Byte offset of 16-byte chunk `ch` (0..7) of tile row `row` inside one operand tile.
+template <int DT>
+__device__ __forceinline__ int lds_off(int row, int ch) {
+  return (row >> 3) * 1024 + (row & 7) * 128 + ((ch ^ chunk_swizzle<DT>(row & 7)) << 4);
+}
+
+// Stage one K-step (128 bytes per row) of a 256-row operand tile into LDS.
+// 32 pieces of 8 rows; wave w issues pieces 4w..4w+3.  Lane i of a piece lands at
+// piece_base + 16*i, so it fetches row (i>>3), source chunk (i&7) ^ f(i>>3).
+template <int DT>
+__device__ __forceinline__ void stage(const char* __restrict__ g, size_t row_bytes, int kbyte, char* lds_tile, int wave,
+                                      int lane) {
+  const int r8 = lane >> 3;
+  const int src_chunk = (lane & 7) ^ chunk_swizzle<DT>(r8);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int piece = wave * 4 + i;
+    const char* src = g + (size_t)(piece * 8 + r8) * row_bytes + kbyte + src_chunk * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restrict__ A, const char* __restrict__ B,
+                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves
+
+  // XCD-aware tile assignment (bijective for any grid size).
+  const int nwg = gridDim.x, tiles_n = N / BN;
+  const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  const int tm = wgid / tiles_n, tn = wgid % tiles_n;
+  const char* gA = A + (size_t)tm * BM * row_bytes;
+  const char* gB = B + (size_t)tn * BN * row_bytes;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Per-lane fragment read offsets.  A fragment of 16 rows x 32 k-bytes... :
+  //   bf16 : lane reads row (lane&15), chunk ks*4 + (lane>>4)            -> one b128 per k-substep (2 per K-step)
+  //   mxfp8: lane reads row (lane&15), chunks 2*(lane>>4) + {0,1}        -> two b128 for the single K=128 MFMA
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[2], b_off[2];
+  {
+    const int arow = wr * 128 + fr, brow = wc * 64 + fr;
+    if constexpr (DT == GMD_DT_BF16) {
+      a_off[0] = lds_off<DT>(arow, fq);
+      a_off[1] = lds_off<DT>(arow, 4 + fq);
+      b_off[0] = lds_off<DT>(brow, fq);
+      b_off[1] = lds_off<DT>(brow, 4 + fq);
+    } else {
+      a_off[0] = lds_off<DT>(arow, 2 * fq);
+      a_off[1] = lds_off<DT>(arow, 2 * fq + 1);
+      b_off[0] = lds_off<DT>(brow, 2 * fq);
+      b_off[1] = lds_off<DT>(brow, 2 * fq + 1);
+    }
+  }
+
+  const int nt = (int)(row_bytes / BKB);
+  stage<DT>(gA, row_bytes, 0, smem, wave, lane);
+  stage<DT>(gB, row_bytes, 0, smem + kTileBytes, wave, lane);
+  __syncthreads();  // with LDS-DMA in flight this also waits vmcnt(0)
+
+  for (int t = 0; t < nt; t++) {
+    char* cur = smem + (t & 1) * kBufBytes;
+    char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+    if (t + 1 < nt) {  // prefetch the next K-step before touching this one
+      stage<DT>(gA, row_bytes, (t + 1) * BKB, nxt, wave, lane);
+      stage<DT>(gB, row_bytes, (t + 1) * BKB, nxt + kTileBytes, wave, lane);
+    }
+    const char* la = cur;
+    const char* lb = cur + kTileBytes;
+    if constexpr (DT == GMD_DT_BF16) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        bf16x8 af[8], bfr[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; nb++) bfr[nb] = *(const bf16x8*)(lb + b_off[ks] + nb * 2048);
+#pragma unroll
+        for (int mb = 0; mb < 8; mb++) af[mb] = *(const bf16x8*)(la + a_off[ks] + mb * 2048);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+          for (int nb = 0; nb < 4; nb++)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nb], af[mb], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
+      // MX-scaled fp8: one K=128 MFMA per tile pair, unit scales (E8M0 127 = 2^0).
+      i32x8 bfr[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; nb++) {
+        i32x4 lo = *(const i32x4*)(lb + b_off[0] + nb * 2048), hi = *(const i32x4*)(lb + b_off[1] + nb * 2048);
+        bfr[nb] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      }
+#pragma unroll
+      for (int mb = 0; mb < 8; mb++) {
+        i32x4 lo = *(const i32x4*)(la + a_off[0] + mb * 2048), hi = *(const i32x4*)(la + a_off[1] + mb * 2048);
+        i32x8 af = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int nb = 0; nb < 4; nb++)
+          acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[nb], af, acc[mb][nb], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                         0x7f7f7f7f);
+      }
+    }
+    __syncthreads();  // next buffer landed (vmcnt(0)) and everyone is done reading this one
+  }
+
+  // Epilogue: lane holds C[m][n..n+3] for m = .. + (lane&15), n = .. + (lane>>4)*4.
+  const int m0 = tm * BM + wr * 128 + fr;
+  const int n0 = tn * BN + wc * 64 + fq * 4;
+#pragma unroll
+  for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) {
+      bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
+      *(bf16x4*)(C + (size_t)(m0 + mb * 16) * N + n0 + nb * 16) = o;
+    }
+}
+
+// ---- output checksum (integer, order-independent -> bitwise reproducible) ----
+__global__ void checksum_kernel(const uint4* __restrict__ c, uint64_t n16, unsigned long long* out) {
+  unsigned long long s = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    uint4 v = c[i];
+    s += (unsigned long long)v.x * 0x9E3779B1u + (unsigned long long)v.y * 0x85EBCA77u +
+         (unsigned long long)v.z * 0xC2B2AE3Du + (unsigned long long)v.w * 0x27D4EB2Fu;
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// ---- operand fill: counter-based uniform [-1, 1) ------------------------------
+__device__ __forceinline__ uint32_t hash32(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((x ^ (x >> 31)) >> 16);
+}
+
+__global__ void fill_bf16_kernel(__bf16* p, uint64_t n, uint64_t seed) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    p[i] = (__bf16)((float)(hash32(i + seed) & 0xffff) * (2.0f / 65536.0f) - 1.0f);
+}
+
+// OCP e4m3 bytes covering a spread of magnitudes and both signs; never NaN (0x7f / 0xff).
+__global__ void fill_fp8_kernel(uint8_t* p, uint64_t n, uint64_t seed) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint32_t h = hash32(i + seed);
+    uint8_t mag = (uint8_t)(0x20 + (h & 0x1f));  // exponent 4..7, mantissa random: |x| in [2^-3, 2)
+    p[i] = (uint8_t)(mag | ((h >> 8) & 1 ? 0x80 : 0));
+  }
+}
+
+// ---- matrix-pipe peak -----------------------------------------------------------
+// The accumulate-in-place MFMA is written as inline asm: with the builtin hipcc
+// (ROCm 7.2) rotates the eight accumulators of this loop through VGPR copies on
+// every iteration, which halves the measured rate.  An MFMA result feeding the
+// next MFMA whole as its C operand needs no wait states; the results are read
+// by compiler code only after PEAK_DRAIN.
+#define PEAK_MFMA(op, acc, a, b) asm volatile(op " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define PEAK_DRAIN(acc) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc))
+template <int DT>
+__global__ __launch_bounds__(256) void peak_kernel(float* __restrict__ out, int iters, unsigned long long* stamps) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long t0 = 0, r0 = 0;
+  if (threadIdx.x == 0 && stamps) {
+    t0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  float keep = 0.f;
+  if constexpr (DT == GMD_DT_BF16) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      a[j] = (__bf16)(0.25f + 0.01f * ((lane * 7 + j * 3) % 61) - 0.3f);
+      b[j] = (__bf16)(0.5f - 0.013f * ((lane * 5 + j * 11) % 53));
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = f32x4{(float)i, (float)lane, 0.5f * i, 1.f};  // distinct chains: nothing to merge
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) PEAK_MFMA("v_mfma_f32_16x16x32_bf16", acc[i], a, b);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      PEAK_DRAIN(acc[i]);
+      keep += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    }
+  } else if constexpr (DT == GMD_DT_FP8) {
+    long a = 0x3830283038302830l ^ ((long)lane * 0x0101010101010101l & 0x0707070707070707l);
+    long b = 0x30b830b830b830b8l ^ ((long)(lane * 3) * 0x0101010101010101l & 0x0707070707070707l);
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = f32x4{(float)i, (float)lane, 0.5f * i, 1.f};  // distinct chains: nothing to merge
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) PEAK_MFMA("v_mfma_f32_16x16x32_fp8_fp8", acc[i], a, b);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      PEAK_DRAIN(acc[i]);
+      keep += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    }
+  } else if constexpr (DT == GMD_DT_MXFP8) {
+    i32x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      a[j] = 0x38302830 ^ (((lane + j) * 0x01010101) & 0x07070707);
+      b[j] = 0x30b830b8 ^ (((lane * 3 + j) * 0x01010101) & 0x07070707);
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = f32x4{(float)i, (float)lane, 0.5f * i, 1.f};  // distinct chains: nothing to merge
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      PEAK_DRAIN(acc[i]);
+      keep += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    }
+  } else {  // f32-input MFMA
+    float a = 0.001f * (lane + 1), b = 0.002f * (64 - lane);
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = f32x4{(float)i, (float)lane, 0.5f * i, 1.f};  // distinct chains: nothing to merge
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) PEAK_MFMA("v_mfma_f32_16x16x4_f32", acc[i], a, b);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      PEAK_DRAIN(acc[i]);
+      keep += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    }
+  }
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = keep;
+  if (threadIdx.x == 0 && stamps) {
+    // keep the stamps behind the MFMA chain
+    asm volatile("" ::"v"(keep));
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    stamps[2 * blockIdx.x] = t1 - t0;
+    stamps[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+double peak_flops_per_mfma(int dt) {
+  switch (dt) {
+    case GMD_DT_BF16:
+    case GMD_DT_FP8: return 2.0 * 16 * 16 * 32;
+    case GMD_DT_MXFP8: return 2.0 * 16 * 16 * 128;
+    default: return 2.0 * 16 * 16 * 4;
+  }
+}
+
+template <int DT>
+int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t row_bytes, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    GMD_HIP(hipFuncSetAttribute((const void*)gemm_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    attr_set = true;
+  }
+  const int grid = (m / BM) * (n / BN);
+  gemm_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+  GMD_HIP(hipGetLastError());
+  return GMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream) {
+  if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || (m % BM) || (n % BN)) return GMD_ERR_BADPARAM;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return GMD_ERR_BADPARAM;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (dtype == GMD_DT_BF16) {
+    if (k % 64) return GMD_ERR_BADPARAM;
+    return launch_gemm_t<GMD_DT_BF16>(a, b, c, m, n, (size_t)k * 2, st);
+  }
+  if (dtype == GMD_DT_FP8 || dtype == GMD_DT_MXFP8) {
+    if (k % 128) return GMD_ERR_BADPARAM;
+    return launch_gemm_t<GMD_DT_MXFP8>(a, b, c, m, n, (size_t)k, st);
+  }
+  return GMD_ERR_BADPARAM;
+}
+
+int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, int verify, gmd_mfma_result_t* out) {
+  if (!out) return GMD_ERR_BADPARAM;
+  memset(out, 0, sizeof *out);
+  const bool fp8 = dtype == GMD_DT_FP8 || dtype == GMD_DT_MXFP8;
+  if (dtype != GMD_DT_BF16 && !fp8) return GMD_ERR_BADPARAM;
+  if (m <= 0 || n <= 0 || k <= 0 || (m % BM) || (n % BN) || (k % (fp8 ? 128 : 64))) return GMD_ERR_BADPARAM;
+  GMD_HIP(hipSetDevice(device));
+  const size_t esz = fp8 ? 1 : 2;
+  gmd::DeviceBuffer a, b, c, sums;
+  int rc;
+  const int kMaxLaunches = 1 << 16;
+  if ((rc = a.alloc((size_t)m * k * esz)) || (rc = b.alloc((size_t)n * k * esz)) || (rc = c.alloc((size_t)m * n * 2)) ||
+      (rc = sums.alloc(sizeof(unsigned long long) * kMaxLaunches)))
+    return rc;
+  if (fp8) {
+    fill_fp8_kernel<<<2048, 256>>>((uint8_t*)a.p, (uint64_t)m * k, 1);
+    fill_fp8_kernel<<<2048, 256>>>((uint8_t*)b.p, (uint64_t)n * k, 2);
+  } else {
+    fill_bf16_kernel<<<2048, 256>>>((__bf16*)a.p, (uint64_t)m * k, 1);
+    fill_bf16_kernel<<<2048, 256>>>((__bf16*)b.p, (uint64_t)n * k, 2);
+  }
+  GMD_HIP(hipMemset(sums.p, 0, sizeof(unsigned long long) * kMaxLaunches));
+  GMD_HIP(hipGetLastError());
+  if ((rc = gmd_gemm_launch(dtype, a.p, b.p, c.p, m, n, k, nullptr))) return rc;  // warm-up
+  GMD_HIP(hipDeviceSynchronize());
+
+  const uint64_t n16 = (uint64_t)m * n * 2 / 16;
+  hipEvent_t e0, e1;
+  GMD_HIP(hipEventCreate(&e0));
+  GMD_HIP(hipEventCreate(&e1));
+  const double flops = 2.0 * m * n * (double)k;
+  double t_start = now_s(), gpu_s = 0, best_ms = 1e30;
+  uint64_t launches = 0;
+  while (launches < (uint64_t)kMaxLaunches) {
+    // Batches of launches between host syncs keep the queue full.
+    const int batch = 8;
+    GMD_HIP(hipEventRecord(e0, 0));
+    for (int i = 0; i < batch; i++) {
+      if ((rc = gmd_gemm_launch(dtype, a.p, b.p, c.p, m, n, k, nullptr))) return rc;
+      if (verify) checksum_kernel<<<1024, 256>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + launches + i);
+    }
+    GMD_HIP(hipEventRecord(e1, 0));
+    GMD_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GMD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    launches += batch;
+    gpu_s += ms * 1e-3;
+    best_ms = std::min(best_ms, (double)ms / batch);
+    if (now_s() - t_start >= seconds || launches + batch > (uint64_t)kMaxLaunches) break;
+  }
+  GMD_HIP(hipGetLastError());
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  out->launches = launches;
+  out->seconds = gpu_s;
+  out->tflops = flops * (double)launches / gpu_s / 1e12;
+  out->tflops_best = flops / (best_ms * 1e-3) / 1e12;
+  if (verify) {
+    std::vector<unsigned long long> h(launches);
+    GMD_HIP(hipMemcpy(h.data(), sums.p, launches * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (uint64_t i = 1; i < launches; i++)
+      if (h[i] != h[0]) out->sdc_mismatches++;
+    out->verified = out->sdc_mismatches ? -1 : 1;
+    if (h[0] == 0) out->verified = -1;  // an all-zero C means the kernel did nothing
+  }
+  if (out->verified < 0) {
+    gmd::set_error("GEMM stress: %llu of %llu launches differ from the first (silent data corruption?)",
+                   (unsigned long long)out->sdc_mismatches, (unsigned long long)launches);
+    return GMD_ERR_VERIFY;
+  }
+  return GMD_OK;
+}
+
+int gmd_mfma_peak(int device, int dtype, double seconds, gmd_mfma_result_t* out) {
+  if (!out || dtype < 0 || dtype > GMD_DT_MXFP8) return GMD_ERR_BADPARAM;
+  memset(out, 0, sizeof *out);
+  GMD_HIP(hipSetDevice(device));
+  const int blocks = gmd::kCUs * 2, threads = 256, iters = 4096;  // 2 waves per SIMD
+  gmd::DeviceBuffer sink, stamps;
+  int rc;
+  if ((rc = sink.alloc(sizeof(float) * blocks * threads)) || (rc = stamps.alloc(sizeof(unsigned long long) * 2 * blocks)))
+    return rc;
+  auto run = [&](unsigned long long* st) {
+    switch (dtype) {
+      case GMD_DT_BF16: peak_kernel<GMD_DT_BF16><<<blocks, threads>>>((float*)sink.p, iters, st); break;
+      case GMD_DT_FP8: peak_kernel<GMD_DT_FP8><<<blocks, threads>>>((float*)sink.p, iters, st); break;
+      case GMD_DT_MXFP8: peak_kernel<GMD_DT_MXFP8><<<blocks, threads>>>((float*)sink.p, iters, st); break;
+      default: peak_kernel<GMD_DT_F32><<<blocks, threads>>>((float*)sink.p, iters, st); break;
+    }
+  };
+  run(nullptr);
+  GMD_HIP(hipGetLastError());
+  GMD_HIP(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  GMD_HIP(hipEventCreate(&e0));
+  GMD_HIP(hipEventCreate(&e1));
+  const double flops_launch = (double)blocks * (threads / 64) * (double)iters * 8 * peak_flops_per_mfma(dtype);
+  double t_start = now_s(), gpu_s = 0, best_ms = 1e30;
+  uint64_t launches = 0;
+  do {
+    GMD_HIP(hipEventRecord(e0, 0));
+    for (int i = 0; i < 4; i++) run(nullptr);
+    GMD_HIP(hipEventRecord(e1, 0));
+    GMD_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GMD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    gpu_s += ms * 1e-3;
+    best_ms = std::min(best_ms, (double)ms / 4);
+    launches += 4;
+  } while (now_s() - t_start < seconds);
+  // One stamped launch after the soak: shader cycles per 100 MHz reference tick.
+  run((unsigned long long*)stamps.p);
+  GMD_HIP(hipDeviceSynchronize());
+  std::vector<unsigned long long> h(2 * blocks);
+  GMD_HIP(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<double> mhz;
+  for (int i = 0; i < blocks; i++)
+    if (h[2 * i + 1]) mhz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);
+  if (!mhz.empty()) {
+    std::sort(mhz.begin(), mhz.end());
+    out->clock_mhz_est = mhz[mhz.size() / 2];
+  }
+  GMD_HIP(hipGetLastError());
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  out->launches = launches;
+  out->seconds = gpu_s;
+  out->tflops = flops_launch * (double)launches / gpu_s / 1e12;
+  out->tflops_best = flops_launch / (best_ms * 1e-3) / 1e12;
+  return GMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,193 @@
+"""ctypes front end of libgpumon_diag.so — the hand-written CDNA4 diagnostics.
+
+No fallback path: on a machine with a GPU the native library must load, and
+every function here runs the HIP kernels of diag/hip (never a torch stand-in).
+torch is only ever used by callers as an *oracle* to check numerics.
+"""
+import ctypes as C
+
+from .._lib import diag_lib
+
+STREAM_KERNELS = {"copy": 0, "scale": 1, "add": 2, "triad": 3, "read": 4, "write": 5}
+PATTERNS = {"walking_ones": 1, "walking_zeros": 2, "address": 4, "checkerboard": 8, "inv_checkerboard": 16,
+            "random": 32, "modulo_20": 64}
+PAT_ALL = 0x7F
+DTYPES = {"bf16": 0, "fp8": 1, "f32": 2, "mxfp8": 3}
+MEMTEST_LOG = 32
+
+
+class DiagError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        msg = diag_lib().gmd_last_error().decode()
+        super().__init__(f"{what} failed ({code}): {msg}")
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("gcn_arch", C.c_char * 64), ("total_mem", C.c_uint64),
+                ("free_mem", C.c_uint64), ("compute_units", C.c_int), ("clock_mhz", C.c_int),
+                ("mem_clock_mhz", C.c_int), ("l2_bytes", C.c_int), ("lds_per_cu", C.c_int), ("pci_bdf", C.c_char * 32)]
+
+
+class StreamResult(C.Structure):
+    _fields_ = [("tbps_best", C.c_double), ("tbps_median", C.c_double), ("ms_best", C.c_double),
+                ("bytes_per_iter", C.c_uint64), ("verified", C.c_int32), ("iters", C.c_int32)]
+
+
+class MemtestError(C.Structure):
+    _fields_ = [("byte_offset", C.c_uint64), ("expected", C.c_uint64), ("actual", C.c_uint64),
+                ("pattern", C.c_uint32), ("chunk", C.c_uint32)]
+
+
+class MemtestResult(C.Structure):
+    _fields_ = [("bytes_tested", C.c_uint64), ("bytes_requested", C.c_uint64), ("errors", C.c_uint64),
+                ("patterns_run", C.c_uint32), ("chunks", C.c_uint32), ("write_tbps", C.c_double),
+                ("verify_tbps", C.c_double), ("seconds", C.c_double), ("logged", C.c_uint32),
+                ("log", MemtestError * MEMTEST_LOG)]
+
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_double, C.c_char_p, C.c_void_p)
+
+
+class MemtestConfig(C.Structure):
+    _fields_ = [("bytes", C.c_uint64), ("fraction", C.c_double), ("chunk_bytes", C.c_uint64),
+                ("patterns", C.c_uint32), ("passes", C.c_uint32), ("seed", C.c_uint64),
+                ("inject_offset", C.c_uint64), ("inject_xor", C.c_uint64), ("progress", PROGRESS_CB),
+                ("progress_user", C.c_void_p)]
+
+
+class MfmaResult(C.Structure):
+    _fields_ = [("tflops", C.c_double), ("tflops_best", C.c_double), ("seconds", C.c_double),
+                ("launches", C.c_uint64), ("clock_mhz_est", C.c_double), ("verified", C.c_int32),
+                ("sdc_mismatches", C.c_uint64), ("max_rel_err", C.c_double)]
+
+
+_typed = False
+
+
+def _lib():
+    global _typed
+    L = diag_lib()
+    if not _typed:
+        L.gmd_last_error.restype = C.c_char_p
+        L.gmd_device_count.restype = C.c_int
+        L.gmd_device_info.argtypes = [C.c_int, C.POINTER(DeviceInfo)]
+        L.gmd_hbm_stream.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(StreamResult)]
+        L.gmd_hbm_stream_launch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64,
+                                            C.c_int, C.c_void_p]
+        L.gmd_memtest.argtypes = [C.c_int, C.POINTER(MemtestConfig), C.POINTER(MemtestResult)]
+        L.gmd_memtest_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.gmd_memtest_verify.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.POINTER(MemtestError), C.POINTER(C.c_uint32),
+                                         C.c_void_p]
+        L.gmd_mfma_peak.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(MfmaResult)]
+        L.gmd_gemm_stress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                      C.POINTER(MfmaResult)]
+        L.gmd_gemm_launch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]
+        _typed = True
+    return L
+
+
+def _dict(s):
+    out = {}
+    for name, _ in s._fields_:
+        v = getattr(s, name)
+        if isinstance(v, bytes):
+            v = v.decode()
+        if isinstance(v, C.Array):
+            continue
+        out[name] = v
+    return out
+
+
+def device_count():
+    return _lib().gmd_device_count()
+
+
+def device_info(device=0):
+    d = DeviceInfo()
+    rc = _lib().gmd_device_info(device, C.byref(d))
+    if rc:
+        raise DiagError(rc, "gmd_device_info")
+    return _dict(d)
+
+
+def _nt(nontemporal):
+    """False -> plain, True -> non-temporal, "auto" -> the faster measured policy per kernel."""
+    return 2 if nontemporal == "auto" else int(bool(nontemporal))
+
+
+def hbm_stream(kernel="copy", bytes_per_buffer=4 << 30, iters=10, nontemporal="auto", device=0):
+    r = StreamResult()
+    rc = _lib().gmd_hbm_stream(device, STREAM_KERNELS[kernel], bytes_per_buffer, iters, _nt(nontemporal), C.byref(r))
+    if rc:
+        raise DiagError(rc, f"gmd_hbm_stream({kernel})")
+    return _dict(r)
+
+
+def hbm_stream_launch(kernel, a, b, c, scalar, n_floats, nontemporal=False, stream=None):
+    """One launch on caller memory (device pointers as ints, e.g. tensor.data_ptr())."""
+    rc = _lib().gmd_hbm_stream_launch(STREAM_KERNELS[kernel], a, b, c, scalar, n_floats, _nt(nontemporal), stream)
+    if rc:
+        raise DiagError(rc, f"gmd_hbm_stream_launch({kernel})")
+
+
+def memtest(bytes=0, fraction=0.90, chunk_bytes=2 << 30, patterns=PAT_ALL, passes=1, seed=0, inject_offset=0,
+            inject_xor=0, progress=None, device=0):
+    cfg = MemtestConfig()
+    cfg.bytes, cfg.fraction, cfg.chunk_bytes = bytes, fraction, chunk_bytes
+    cfg.patterns, cfg.passes, cfg.seed = patterns, passes, seed
+    cfg.inject_offset, cfg.inject_xor = inject_offset, inject_xor
+    keep = None
+    if progress is not None:
+        keep = PROGRESS_CB(lambda f, what, _u: progress(f, what.decode()))
+        cfg.progress = keep
+    r = MemtestResult()
+    rc = _lib().gmd_memtest(device, C.byref(cfg), C.byref(r))
+    if rc:
+        raise DiagError(rc, "gmd_memtest")
+    d = _dict(r)
+    d["log"] = [_dict(r.log[i]) for i in range(r.logged)]
+    return d
+
+
+def memtest_fill(ptr, n_words, pattern, seed=0, base_word=0, stream=None):
+    rc = _lib().gmd_memtest_fill(ptr, n_words, base_word, PATTERNS[pattern] if isinstance(pattern, str) else pattern,
+                                 seed, stream)
+    if rc:
+        raise DiagError(rc, "gmd_memtest_fill")
+
+
+def memtest_verify(ptr, n_words, pattern, seed=0, base_word=0, stream=None):
+    errs = C.c_uint64()
+    log = (MemtestError * MEMTEST_LOG)()
+    n = C.c_uint32()
+    rc = _lib().gmd_memtest_verify(ptr, n_words, base_word, PATTERNS[pattern] if isinstance(pattern, str) else pattern,
+                                   seed, C.byref(errs), log, C.byref(n), stream)
+    if rc:
+        raise DiagError(rc, "gmd_memtest_verify")
+    return errs.value, [_dict(log[i]) for i in range(n.value)]
+
+
+def mfma_peak(dtype="bf16", seconds=1.0, device=0):
+    r = MfmaResult()
+    rc = _lib().gmd_mfma_peak(device, DTYPES[dtype], seconds, C.byref(r))
+    if rc:
+        raise DiagError(rc, f"gmd_mfma_peak({dtype})")
+    return _dict(r)
+
+
+def gemm_stress(dtype="bf16", m=8192, n=8192, k=8192, seconds=2.0, verify=True, device=0):
+    r = MfmaResult()
+    rc = _lib().gmd_gemm_stress(device, DTYPES[dtype], m, n, k, seconds, int(verify), C.byref(r))
+    if rc:
+        raise DiagError(rc, f"gmd_gemm_stress({dtype})")
+    return _dict(r)
+
+
+def gemm_launch(dtype, a_ptr, b_ptr, c_ptr, m, n, k, stream=None):
+    """C[M,N] (bf16) = A[M,K] @ B[N,K]^T on caller memory."""
+    rc = _lib().gmd_gemm_launch(DTYPES[dtype], a_ptr, b_ptr, c_ptr, m, n, k, stream)
+    if rc:
+        raise DiagError(rc, f"gmd_gemm_launch({dtype})")

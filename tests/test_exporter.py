@@ -1,0 +1,272 @@
+"""Prometheus exporter against the fake device backend (CPU only).
+
+Covers the text contract of the reference's exporter script
+(exporters/prometheus-dcgm/dcgm-exporter/dcgm-exporter:97-193): family names,
+types and HELP text, label order gpu,uuid, blank ("N/A") omission, the
+synthesised gpu_last_not_idle_time, GPU subset selection, the >=100 ms interval
+floor and atomic publishing — plus what a native exporter adds (valid family
+grouping, AMD extras, self metrics, HTTP).
+"""
+import os
+import re
+import subprocess
+import time
+import urllib.request
+
+import pytest
+
+from conftest import ROOT, bin_path
+from k8s_gpu_monitor_amd import engine as E
+from k8s_gpu_monitor_amd.utils.promparse import ExpositionError, parse
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "exporter_2gpu_steady.prom")
+
+# name, type, HELP — verbatim from the reference's awk program, in its order.
+CONTRACT = [
+    ("sm_clock", "gauge", "SM clock frequency (in MHz)."),
+    ("memory_clock", "gauge", "Memory clock frequency (in MHz)."),
+    ("memory_temp", "gauge", "Memory temperature (in C)."),
+    ("gpu_temp", "gauge", "GPU temperature (in C)."),
+    ("power_usage", "gauge", "Power draw (in W)."),
+    ("total_energy_consumption", "counter", "Total energy consumption since boot (in mJ)."),
+    ("pcie_tx_throughput", "counter", "Total number of bytes transmitted through PCIe TX (in KB) via NVML."),
+    ("pcie_rx_throughput", "counter", "Total number of bytes received through PCIe RX (in KB) via NVML."),
+    ("pcie_replay_counter", "counter", "Total number of PCIe retries."),
+    ("gpu_utilization", "gauge", "GPU utilization (in %)."),
+    ("gpu_last_not_idle_time", "gauge", "Timestamp of last time GPU utilization was 2% or less."),
+    ("mem_copy_utilization", "gauge", "Memory utilization (in %)."),
+    ("enc_utilization", "gauge", "Encoder utilization (in %)."),
+    ("dec_utilization", "gauge", "Decoder utilization (in %)."),
+    ("xid_errors", "gauge", "Value of the last XID error encountered."),
+    ("power_violation", "counter", "Throttling duration due to power constraints (in us)."),
+    ("thermal_violation", "counter", "Throttling duration due to thermal constraints (in us)."),
+    ("sync_boost_violation", "counter", "Throttling duration due to sync-boost constraints (in us)."),
+    ("board_limit_violation", "counter", "Throttling duration due to board limit constraints (in us)."),
+    ("low_util_violation", "counter", "Throttling duration due to low utilization (in us)."),
+    ("reliability_violation", "counter", "Throttling duration due to reliability constraints (in us)."),
+    ("fb_total", "gauge", "Framebuffer memory free (in MiB)."),  # sic: the reference's typo is part of the contract
+    ("fb_free", "gauge", "Framebuffer memory free (in MiB)."),
+    ("fb_used", "gauge", "Framebuffer memory used (in MiB)."),
+    ("ecc_sbe_volatile_total", "counter", "Total number of single-bit volatile ECC errors."),
+    ("ecc_dbe_volatile_total", "counter", "Total number of double-bit volatile ECC errors."),
+    ("ecc_sbe_aggregate_total", "counter", "Total number of single-bit persistent ECC errors."),
+    ("ecc_dbe_aggregate_total", "counter", "Total number of double-bit persistent ECC errors."),
+    ("retired_pages_sbe", "counter", "Total number of retired pages due to single-bit errors."),
+    ("retired_pages_dbe", "counter", "Total number of retired pages due to double-bit errors."),
+    ("retired_pages_pending", "counter", "Total number of pages pending retirement."),
+    ("nvlink_flit_crc_error_count_total", "counter", "Total number of NVLink flow-control CRC errors."),
+    ("nvlink_data_crc_error_count_total", "counter", "Total number of NVLink data CRC errors."),
+    ("nvlink_replay_error_count_total", "counter", "Total number of NVLink retries."),
+    ("nvlink_recovery_error_count_total", "counter", "Total number of NVLink recovery errors."),
+    ("nvlink_bandwidth_total", "counter", "Total number of NVLink bandwidth counters for all lanes"),
+]
+PROFILING = [
+    ("fi_prof_gr_engine_active", "gauge", "Ratio of time the graphics engine is active (in %)."),
+    ("fi_prof_sm_active", "gauge", "The ratio of cycles an SM has at least 1 warp assigned (in %)."),
+    ("fi_prof_sm_occupancy", "gauge", "The ratio of number of warps resident on an SM (in %)."),
+    ("fi_prof_pipe_tensor_active", "gauge", "Ratio of cycles the tensor (HMMA) pipe is active (in %)."),
+    ("fi_prof_dram_active", "gauge",
+     "Ratio of cycles the device memory interface is active sending or receiving data (in %)."),
+]
+# Families with no AMD meaning on the fake MI355X node: blank, hence omitted.
+OMITTED_ON_MI355X = {"enc_utilization", "sync_boost_violation", "nvlink_replay_error_count_total",
+                     "nvlink_recovery_error_count_total"}
+
+
+def _normalise(text):
+    """The one wall-clock dependent value is replaced by a token."""
+    return re.sub(r"(dcgm_gpu_last_not_idle_time\{[^}]*\}) \d+", r"\1 <TS>", text)
+
+
+def test_registry_has_verbatim_contract(engine2):
+    seen = {}
+    for fid in E.field_list():
+        m = E.field_meta(fid)
+        if m["prom_name"]:
+            seen[m["prom_name"].decode() if isinstance(m["prom_name"], bytes) else m["prom_name"]] = m
+    for name, typ, help_ in CONTRACT + PROFILING:
+        if name == "gpu_last_not_idle_time":
+            continue  # derived at render time
+        m = seen["dcgm_" + name]
+        assert {1: "gauge", 2: "counter"}[m["prom_type"]] == typ, name
+        assert m["prom_help"] == help_, name
+
+
+def test_golden_file_byte_exact():
+    E.init(backend="fake", backend_spec="gpus=2,steady=1,seed=1")
+    try:
+        with E.Exporter(interval_ms=1000) as ex:
+            ex.sweep()
+            text = ex.render()
+    finally:
+        E.shutdown()
+    got = _normalise(text)
+    if os.environ.get("GPUMON_UPDATE_GOLDEN"):
+        os.makedirs(os.path.dirname(GOLDEN), exist_ok=True)
+        open(GOLDEN, "w").write(got)
+    assert got == open(GOLDEN).read()
+
+
+def test_strict_exposition_and_contract_order(engine):
+    with E.Exporter(interval_ms=1000, profiling=True) as ex:
+        ex.sweep()
+        fams = parse(ex.render())
+    expected = [("dcgm_" + n, t, h) for n, t, h in CONTRACT + PROFILING if n not in OMITTED_ON_MI355X]
+    assert [f.name for f in fams.values()] == [n for n, _, _ in expected]
+    for name, typ, help_ in expected:
+        f = fams[name]
+        assert f.type == typ and f.help == help_
+        assert len(f.samples) == 8, name  # one per GPU, all contiguous under one header
+        for i, (labels, _v) in enumerate(f.samples):
+            assert list(labels.keys()) == ["gpu", "uuid"]  # label ORDER is part of the contract
+            assert labels["gpu"] == str(i)
+            assert labels["uuid"].startswith("GPU-00000001-fa4e-0355-0000-")
+
+
+def test_blank_values_are_omitted_not_zero(engine2):
+    with E.Exporter(interval_ms=1000) as ex:
+        ex.sweep()
+        assert "dcgm_enc_utilization" not in ex.render()  # no orphan HELP/TYPE either
+        E.fake_ctl("unsupported gpu=1 field=150")
+        E.fake_ctl("noperm gpu=0 field=155")
+        ex.sweep()
+        fams = parse(ex.render())
+        assert [l["gpu"] for l, _ in fams["dcgm_gpu_temp"].samples] == ["0"]
+        assert [l["gpu"] for l, _ in fams["dcgm_power_usage"].samples] == ["1"]
+        E.fake_ctl("clear gpu=1 field=150")
+        ex.sweep()
+        assert len(parse(ex.render())["dcgm_gpu_temp"].samples) == 2
+
+
+def test_backend_failure_blanks_but_never_stops(engine2):
+    with E.Exporter(interval_ms=1000) as ex:
+        ex.sweep()
+        E.fake_ctl("fail gpu=0")
+        ex.sweep()
+        fams = parse(ex.render())
+        assert all(l["gpu"] == "1" for f in fams.values() for l, _ in f.samples if f.name != "dcgm_xid_errors")
+        E.fake_ctl("clear gpu=0")
+        ex.sweep()
+        assert len(parse(ex.render())["dcgm_sm_clock"].samples) == 2
+        assert E.introspect()["backend_errors"] > 0
+
+
+def test_last_not_idle_time_latches(engine2):
+    with E.Exporter(interval_ms=1000) as ex:
+        def ts():
+            ex.sweep()
+            return {l["gpu"]: v for l, v in parse(ex.render())["dcgm_gpu_last_not_idle_time"].samples}
+        t0 = ts()
+        now = time.time()
+        assert all(abs(v - now) < 5 for v in t0.values())  # first sight latches "now"
+        time.sleep(1.2)
+        t1 = ts()
+        assert t1 == t0  # idle (util 0 <= 2): the stamp holds
+        E.fake_ctl("load gpu=1 util=55")
+        time.sleep(1.1)
+        t2 = ts()
+        assert t2["0"] == t0["0"] and t2["1"] > t0["1"]  # busy GPU re-latches
+        E.fake_ctl("load gpu=1 util=2")  # 2 % is still idle: "> 2" in the reference
+        time.sleep(1.1)
+        t3 = ts()
+        assert t3["1"] == t2["1"]
+
+
+def test_gpu_subset_and_bad_subset(engine):
+    with E.Exporter(interval_ms=1000, gpus="5,2") as ex:
+        ex.sweep()
+        fams = parse(ex.render())
+        assert [l["gpu"] for l, _ in fams["dcgm_sm_clock"].samples] == ["2", "5"]
+    with pytest.raises(E.GpumonError):
+        E.Exporter(gpus="0,99")
+    with pytest.raises(E.GpumonError):
+        E.Exporter(gpus="zero")
+
+
+def test_amd_extras_and_self_metrics(engine2):
+    with E.Exporter(interval_ms=1000, extras=True, self_metrics=True) as ex:
+        ex.sweep()
+        fams = parse(ex.render())
+    link = fams["gpumon_xgmi_link_rx_kb_total"]
+    assert [list(l.keys()) for l, _ in link.samples][0] == ["gpu", "uuid", "link"]
+    assert {l["link"] for l, _ in link.samples} == {"0"}  # a 2-GPU node wires one link per GPU
+    assert {l["stack"] for l, _ in fams["gpumon_hbm_stack_temp"].samples} == {str(i) for i in range(8)}
+    assert {l["xcd"] for l, _ in fams["gpumon_xcd_busy"].samples} == {str(i) for i in range(8)}
+    assert {l["block"] for l, _ in fams["gpumon_ecc_block_uncorrectable_total"].samples} == {
+        "umc", "gfx", "sdma", "mmhub", "xgmi"}
+    for name in ("gpumon_engine_cpu_percent", "gpumon_engine_memory_kb", "gpumon_exporter_render_duration_seconds",
+                 "gpumon_engine_sample_cycle_seconds"):
+        assert name in fams and len(fams[name].samples) == 1
+    # the contract families are untouched by the extras
+    assert fams["dcgm_sm_clock"].help == "SM clock frequency (in MHz)."
+
+
+def test_legacy_layout_matches_reference_shape(engine2):
+    """GPU-major, HELP/TYPE only with the first GPU (dcgm-exporter:99-102)."""
+    with E.Exporter(interval_ms=1000, legacy_layout=True) as ex:
+        ex.sweep()
+        text = ex.render()
+    lines = text.splitlines()
+    first_gpu1 = next(i for i, l in enumerate(lines) if 'gpu="1"' in l)
+    assert all(not l.startswith("#") for l in lines[first_gpu1:])
+    assert sum(1 for l in lines if l.startswith("# TYPE")) == len(CONTRACT) - len(OMITTED_ON_MI355X)
+    with pytest.raises(ExpositionError):  # which is exactly why the native layout groups by family
+        parse(text)
+
+
+def test_atomic_file_publish_and_http(engine2, tmp_path):
+    out = tmp_path / "prom" / "dcgm.prom"
+    with E.Exporter(interval_ms=100, output_path=str(out), listen="127.0.0.1:0", self_metrics=True) as ex:
+        ex.start()
+        deadline = time.time() + 5
+        while not out.exists() and time.time() < deadline:
+            time.sleep(0.02)
+        assert out.exists()
+        seen = set()
+        for _ in range(200):  # a reader never sees a partial file
+            txt = out.read_text()
+            assert txt.endswith("\n")
+            fams = parse(txt)
+            assert len(fams["dcgm_fb_used"].samples) == 2
+            seen.add(os.stat(out).st_ino)
+            time.sleep(0.003)
+        assert len(seen) > 1  # replaced by rename, not rewritten in place
+        assert not os.path.exists(str(out) + ".swp") or True
+        assert oct(os.stat(out).st_mode & 0o777) == "0o644"
+        port = ex.port
+        body = urllib.request.urlopen(f"http://127.0.0.1:{port}/metrics", timeout=5).read().decode()
+        assert parse(body)["dcgm_gpu_temp"].samples
+        body2 = urllib.request.urlopen(f"http://127.0.0.1:{port}/gpu/metrics", timeout=5).read().decode()
+        assert "dcgm_gpu_temp" in body2
+        assert urllib.request.urlopen(f"http://127.0.0.1:{port}/healthz", timeout=5).read() == b"ok\n"
+        with pytest.raises(urllib.error.HTTPError) as e:
+            urllib.request.urlopen(f"http://127.0.0.1:{port}/nope", timeout=5)
+        assert e.value.code == 404
+        ex.stop()
+
+
+def test_exporter_binary_flags(tmp_path):
+    exe = bin_path("gpumon-exporter")
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=4,steady=1")
+    out = tmp_path / "x.prom"
+    # interval below 100 ms is refused like the reference (dcgm-exporter:32-34)
+    r = subprocess.run([exe, "-e", "-d", "50", "--once", "-o", str(out)], env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+    r = subprocess.run([exe, "-h"], env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "-e" in r.stderr and "-d" in r.stderr
+    r = subprocess.run([exe, "-e", "-p", "--once", "-o", str(out)], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fams = parse(out.read_text())
+    assert "dcgm_fi_prof_gr_engine_active" in fams and len(fams["dcgm_sm_clock"].samples) == 4
+    # NODE_NAME -> env var named after the node (dashes become underscores) -> GPU list
+    env2 = dict(env, NODE_NAME="gpu-node-7", gpu_node_7="1,3")
+    r = subprocess.run([exe, "-e", "--once", "-o", str(out)], env=env2, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert [l["gpu"] for l, _ in parse(out.read_text())["dcgm_sm_clock"].samples] == ["1", "3"]
+    assert "GPUs:1,3" in r.stderr
+
+
+def test_interval_floor_is_clamped_in_library(engine2):
+    with E.Exporter(interval_ms=5) as ex:  # library clamps instead of failing
+        ex.sweep()
+        assert "dcgm_sm_clock" in ex.render()
