@@ -62,7 +62,17 @@ int main(int argc, char** argv) {
       return 1;
     }
     for (int i = 0; i < 100; i++) {  // 10 s grace, then force
-      if (kill((pid_t)pid, 0) != 0) {
+      // Gone, or a zombie its parent has not reaped yet: either way it has stopped.
+      bool stopped = kill((pid_t)pid, 0) != 0;
+      if (!stopped) {
+        char path[64], state = 0;
+        snprintf(path, sizeof path, "/proc/%ld/stat", pid);
+        if (FILE* s = fopen(path, "r")) {
+          if (fscanf(s, "%*d (%*[^)]) %c", &state) == 1 && state == 'Z') stopped = true;
+          fclose(s);
+        }
+      }
+      if (stopped) {
         unlink(pid_file.c_str());
         printf("Host engine successfully terminated.\n");
         return 0;

@@ -176,7 +176,24 @@ gm_status_t do_init(Global& g, const gm_init_params_t* p) {
   }
   gm_status_t st;
   std::string err;
-  g.remote = make_remote_engine(address, is_unix, p->mode == GM_MODE_START_HOSTENGINE ? 15000 : 5000, &st, &err);
+  if (p->mode == GM_MODE_START_HOSTENGINE) {
+    // Short connect attempts while the child comes up, so that a child that died
+    // (bad binary, backend init failure) is reported at once instead of after the
+    // whole grace period.
+    st = GM_ST_CONNECTION_NOT_VALID;
+    for (int64_t t0 = monotonic_us(); monotonic_us() - t0 < 15000000 && !g.remote;) {
+      int status;
+      if (waitpid(g.child, &status, WNOHANG) == g.child) {
+        err = strprintf("host engine child exited early (status 0x%x)", status);
+        g.child = -1;
+        st = GM_ST_CHILD_SPAWN_FAILED;
+        break;
+      }
+      g.remote = make_remote_engine(address, is_unix, 200, &st, &err);
+    }
+  } else {
+    g.remote = make_remote_engine(address, is_unix, 5000, &st, &err);
+  }
   if (!g.remote) {
     GM_LOGE("%s", err.c_str());
     stop_child(g);

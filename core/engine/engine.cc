@@ -558,8 +558,12 @@ void LocalEngine::rebuild_watch_table() {
         else if (sw.keep_samples != 0) sw.keep_samples = w.keep_samples == 0 ? 0 : std::max(sw.keep_samples, w.keep_samples);
       }
     }
+    // Keep the running schedule, but a newly added faster watch must not wait out
+    // the slower period that was already in flight.
+    const int64_t now = monotonic_us();
     for (int s = 0; s < nslots; s++)
-      if (nw[s].freq_us && g->watch[s].freq_us) nw[s].next_due_mono = g->watch[s].next_due_mono;
+      if (nw[s].freq_us && g->watch[s].freq_us && g->watch[s].next_due_mono)
+        nw[s].next_due_mono = std::min(g->watch[s].next_due_mono, now + nw[s].freq_us);
     g->watch.swap(nw);
   }
   watch_gen_++;

@@ -31,7 +31,15 @@ GM_ST_VER_MISMATCH = -19
 GM_ST_TIMEOUT = -20
 GM_ST_DUPLICATE_KEY = -21
 GM_ST_NOT_FOUND = -23
+GM_ST_CHILD_SPAWN_FAILED = -24
 GM_ST_INSUFFICIENT_SIZE = -25
+GM_ST_MEMORY = -4
+GM_ST_FUNCTION_NOT_FOUND = -9
+GM_ST_NO_PERMISSION = -10
+GM_ST_STALE_DATA = -14
+GM_ST_GROUP_INCOMPATIBLE = -17
+GM_ST_MAX_LIMIT = -18
+GM_ST_IN_USE = -22
 
 GM_FT_INT64, GM_FT_DOUBLE, GM_FT_STRING = 1, 2, 3
 GM_VS_OK, GM_VS_BLANK, GM_VS_NOT_SUPPORTED, GM_VS_NO_PERMISSION, GM_VS_ERROR = 0, 1, 2, 3, 4

@@ -224,7 +224,7 @@ def test_cli_tools_against_daemon(daemon):
     assert "-" in run("ps", "-c", "1").splitlines()[2]
     out = run("inject", "-g", "1", "-f", "gpu_temp", "-v", "123", "--hold", "2000")
     assert "Successfully injected" in out
-    assert " 123 " in run("dmon", "-c", "1", "-e", "150")
+    assert run("dmon", "-c", "1", "-e", "150").splitlines()[2].split() == ["1", "123"]
     r = subprocess.run([bin_path("gpumon"), "fields"], capture_output=True, text=True)
     assert "dcgm_sm_clock" in r.stdout and "gpumon_xgmi_link_rx_kb_total" in r.stdout
 
