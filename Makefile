@@ -22,7 +22,8 @@ CORE_SRC := core/common/util.cc core/common/json.cc core/fields.cc \
             core/exporter/views.cc core/exporter/rest.cc core/exporter/pod_exporter.cc core/capi.cc
 CORE_OBJ := $(CORE_SRC:%.cc=$(BUILD)/obj/%.o)
 BINS     := gpumon gpumon-exporter gpumon-hostengine gpumon-pod-exporter
-DIAG_HIP := diag/hip/hbm_stream.hip diag/hip/memtest.hip diag/hip/mfma_gemm.hip diag/hip/diag_api.hip
+DIAG_HIP := diag/hip/hbm_stream.hip diag/hip/memtest.hip diag/hip/mfma_gemm.hip diag/hip/diag_api.hip \
+            diag/rccl/rccl_sweep.hip
 DIAG_OBJ := $(DIAG_HIP:%.hip=$(BUILD)/obj/%.o)
 HIPFLAGS += --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Idiag -Wno-unused-result
 
@@ -49,12 +50,12 @@ $(BUILD)/obj/%.o: %.hip
 
 diag: $(BUILD)/libgpumon_diag.so $(BUILD)/bin/gpumon-diag
 $(BUILD)/libgpumon_diag.so: $(DIAG_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -ldl
 
-$(BUILD)/bin/gpumon-diag: cmd/gpumon-diag.cc diag/rccl/rccl_sweep.cc $(BUILD)/libgpumon_diag.so $(BUILD)/libgpumon.so
+$(BUILD)/bin/gpumon-diag: cmd/gpumon-diag.cc cmd/cli_common.h diag/gpumon_diag.h $(BUILD)/libgpumon_diag.so $(BUILD)/libgpumon.so
 	@mkdir -p $(dir $@)
-	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -Idiag -o $@ cmd/gpumon-diag.cc diag/rccl/rccl_sweep.cc \
-	    -L$(BUILD) -lgpumon_diag -lgpumon -Wl,-rpath,'$$ORIGIN/..' -ldl -pthread
+	$(CXX) $(CXXFLAGS) -fvisibility=default -o $@ $< -L$(BUILD) -lgpumon_diag -lgpumon \
+	    -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath-link,$(ROCM)/lib $(LDFLAGS)
 
 # ---- tests -------------------------------------------------------------------
 TESTS := $(patsubst tests/cpp/%.cc,$(BUILD)/tests/%,$(wildcard tests/cpp/*.cc))

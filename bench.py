@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Headline benchmark: one active-diagnostics step per GPU while the node exporter
+monitors every GPU at 1 s and is scraped over HTTP.
+
+A step, on every rank (= one MI355X), runs the whole diag suite once:
+  hbm      read / write / copy / triad STREAM kernels over 4 GiB buffers
+  memtest  one pattern fill + recompute-verify over a 4 GiB buffer
+  bf16     GEMM 8192^3 on the MFMA kernel, G launches, random data
+  mxfp8    GEMM 8192^3 on the scaled-MFMA kernel, G launches, random data
+  rccl     all-reduce / all-gather / all-to-all of 1 GiB over xGMI   (N > 1)
+  scrape   rank 0 fetches /metrics from the gpumon-exporter child process
+The exporter child is the production binary with the amdsmi backend, watching all
+of the node's GPUs at 1 s with profiling + AMD extra families; its CPU time is
+read from /proc over the timed window.
+
+`value` is the aggregate bf16 GEMM rate of the job (sum over ranks); the other
+headline numbers (HBM TB/s, MX-fp8 TFLOPS, RCCL bus bandwidth, scrape p50,
+exporter CPU %) are in `extras`.  Nothing is skipped in the timed region and
+per-phase times come from HIP events on the stream the phases run on.
+"""
+import argparse
+import json
+import os
+import re
+import signal
+import statistics
+import subprocess
+import sys
+import threading
+import time
+import urllib.request
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+GEMM_DIM = 8192
+HBM_BYTES = 4 << 30
+COLL_BYTES = 1 << 30
+MEMTEST_PATTERN = "random"
+
+
+class ExporterChild:
+    """gpumon-exporter as a child process (started before this process touches the GPU)."""
+
+    def __init__(self):
+        from k8s_gpu_monitor_amd._lib import binary
+        self.proc = subprocess.Popen(
+            [binary("gpumon-exporter"), "-e", "-p", "-o", "", "-d", "1000", "--extras", "--self-metrics", "--listen",
+             "127.0.0.1:0"], stderr=subprocess.PIPE, text=True, env=dict(os.environ, GPUMON_BACKEND="amdsmi"))
+        self.port = None
+        self.log = []
+        deadline = time.time() + 60
+        while time.time() < deadline:
+            line = self.proc.stderr.readline()
+            if not line:
+                break
+            self.log.append(line.rstrip())
+            m = re.search(r"Serving /metrics on port (\d+)", line)
+            if m:
+                self.port = int(m.group(1))
+                break
+        if self.port is None:
+            self.stop()
+            raise RuntimeError("gpumon-exporter did not come up:\n" + "\n".join(self.log))
+        threading.Thread(target=lambda: [self.log.append(l.rstrip()) for l in self.proc.stderr], daemon=True).start()
+        self.url = f"http://127.0.0.1:{self.port}/metrics"
+        self.tck = os.sysconf("SC_CLK_TCK")
+
+    def cpu_seconds(self):
+        """On-CPU time of all the child's threads: schedstat is in ns, /proc/stat ticks are 10 ms."""
+        total, ok = 0, False
+        try:
+            for t in os.listdir(f"/proc/{self.proc.pid}/task"):
+                with open(f"/proc/{self.proc.pid}/task/{t}/schedstat") as f:
+                    total += int(f.read().split()[0])
+                    ok = True
+        except OSError:
+            ok = False
+        if ok:
+            return total / 1e9
+        with open(f"/proc/{self.proc.pid}/stat") as f:
+            rest = f.read().rsplit(")", 1)[1].split()
+        return (int(rest[11]) + int(rest[12])) / self.tck  # utime + stime
+
+    def rss_kb(self):
+        with open(f"/proc/{self.proc.pid}/status") as f:
+            for line in f:
+                if line.startswith("VmRSS:"):
+                    return int(line.split()[1])
+        return 0
+
+    def scrape(self):
+        t0 = time.perf_counter()
+        body = urllib.request.urlopen(self.url, timeout=10).read()
+        return (time.perf_counter() - t0) * 1e3, body
+
+    def stop(self):
+        if self.proc.poll() is None:
+            self.proc.send_signal(signal.SIGTERM)
+            try:
+                self.proc.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                self.proc.kill()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gemm-launches", type=int, default=8, help="GEMM launches per dtype per step")
+    ap.add_argument("--no-exporter", action="store_true", help="debug: skip the exporter child and the scrape phase")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit(f"--gpus {a.gpus} needs a launcher: python -m torch.distributed.run --nnodes=1 --nproc-per-node "
+                     f"{a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    exporter = None
+    if rank == 0 and not a.no_exporter:
+        exporter = ExporterChild()  # before any HIP call in this process
+
+    import torch
+    import torch.distributed as dist
+    from k8s_gpu_monitor_amd.ops import diag
+    from k8s_gpu_monitor_amd.parallel.collectives import busbw_factor
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    try:
+        result = run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor)
+    finally:
+        if exporter:
+            exporter.stop()
+        if world > 1:
+            dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor):
+    G, D = a.gemm_launches, GEMM_DIM
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    # ---- buffers (resident for the whole run) ----
+    nf = HBM_BYTES // 4
+    ha = torch.empty(nf, dtype=torch.float32, device=dev).normal_(generator=g)
+    hb = torch.empty(nf, dtype=torch.float32, device=dev).normal_(generator=g)
+    hc = torch.empty(nf, dtype=torch.float32, device=dev)
+    sink = torch.zeros(1 << 16, dtype=torch.float32, device=dev)
+    A16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev).normal_(generator=g)
+    B16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev).normal_(generator=g)
+    C16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev)
+    A8 = torch.empty(D, D, dtype=torch.float32, device=dev).normal_(generator=g).to(torch.float8_e4m3fn)
+    B8 = torch.empty(D, D, dtype=torch.float32, device=dev).normal_(generator=g).to(torch.float8_e4m3fn)
+    C8 = torch.empty(D, D, dtype=torch.bfloat16, device=dev)
+    if world > 1:
+        ne = COLL_BYTES // 2
+        ar = torch.empty(ne, dtype=torch.bfloat16, device=dev).normal_(generator=g)
+        ag_in = ar[: ne // world]
+        ag_out = torch.empty(ne, dtype=torch.bfloat16, device=dev)
+        a2a_out = torch.empty(ne, dtype=torch.bfloat16, device=dev)
+
+    phases = ["hbm_read", "hbm_write", "hbm_copy", "hbm_triad", "memtest", "gemm_bf16", "gemm_mxfp8"]
+    if world > 1:
+        phases += ["all_reduce", "all_gather", "all_to_all"]
+    total_steps = a.warmup + a.steps
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(phases) + 1)] for _ in range(total_steps)]
+    scrape_ms, memtest_errors, scrape_bytes = [], 0, 0
+
+    def step(i):
+        nonlocal memtest_errors, scrape_bytes
+        e = ev[i]
+        k = 0
+        e[k].record(stream)
+        diag.hbm_stream_launch("read", ha.data_ptr(), 0, sink.data_ptr(), 0.0, nf, "auto", sptr)
+        k += 1; e[k].record(stream)
+        diag.hbm_stream_launch("write", hc.data_ptr(), 0, 0, 1.5, nf, "auto", sptr)
+        k += 1; e[k].record(stream)
+        diag.hbm_stream_launch("copy", ha.data_ptr(), 0, hc.data_ptr(), 0.0, nf, "auto", sptr)
+        k += 1; e[k].record(stream)
+        diag.hbm_stream_launch("triad", ha.data_ptr(), hb.data_ptr(), hc.data_ptr(), 0.5, nf, "auto", sptr)
+        k += 1; e[k].record(stream)
+        diag.memtest_fill(hc.data_ptr(), HBM_BYTES // 8, MEMTEST_PATTERN, seed=i, stream=sptr)
+        errs, _ = diag.memtest_verify(hc.data_ptr(), HBM_BYTES // 8, MEMTEST_PATTERN, seed=i, stream=sptr)
+        memtest_errors += errs
+        k += 1; e[k].record(stream)
+        for _ in range(G):
+            diag.gemm_launch("bf16", A16.data_ptr(), B16.data_ptr(), C16.data_ptr(), D, D, D, sptr)
+        k += 1; e[k].record(stream)
+        for _ in range(G):
+            diag.gemm_launch("mxfp8", A8.data_ptr(), B8.data_ptr(), C8.data_ptr(), D, D, D, sptr)
+        k += 1; e[k].record(stream)
+        if world > 1:
+            dist.all_reduce(ar)
+            k += 1; e[k].record(stream)
+            dist.all_gather_into_tensor(ag_out, ag_in)
+            k += 1; e[k].record(stream)
+            dist.all_to_all_single(a2a_out, ar)
+            k += 1; e[k].record(stream)
+            if i % 8 == 7:  # keep the all-reduced values bounded
+                ar.mul_(1.0 / world ** 8)
+        if exporter is not None:
+            ms, body = exporter.scrape()
+            if i >= a.warmup:
+                scrape_ms.append(ms)
+                scrape_bytes = len(body)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    cpu0 = exporter.cpu_seconds() if exporter else 0.0
+    t0 = time.perf_counter()
+    for i in range(a.warmup, total_steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    cpu1 = exporter.cpu_seconds() if exporter else 0.0
+
+    # ---- reduce over ranks ----
+    ph_ms = torch.zeros(len(phases), dtype=torch.float64)
+    for i in range(a.warmup, total_steps):
+        for k in range(len(phases)):
+            ph_ms[k] += ev[i][k].elapsed_time(ev[i][k + 1])
+    ph_ms /= a.steps
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ph_dev = ph_ms.to(dev)
+    ph_max = ph_dev.clone()
+    errs_t = torch.tensor([memtest_errors], dtype=torch.int64, device=dev)
+    gemm_flops = 2.0 * D * D * D * G
+    # per-rank rates, summed over ranks = the job's aggregate
+    rates = torch.tensor([gemm_flops / (ph_ms[5].item() * 1e-3) / 1e12, gemm_flops / (ph_ms[6].item() * 1e-3) / 1e12,
+                          HBM_BYTES / (ph_ms[0].item() * 1e-3) / 1e12, HBM_BYTES / (ph_ms[1].item() * 1e-3) / 1e12,
+                          2 * HBM_BYTES / (ph_ms[2].item() * 1e-3) / 1e12, 3 * HBM_BYTES / (ph_ms[3].item() * 1e-3) / 1e12,
+                          2 * HBM_BYTES / (ph_ms[4].item() * 1e-3) / 1e12], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(errs_t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(rates, op=dist.ReduceOp.SUM)
+    elapsed = t_el.item()
+    ph_max = ph_max.cpu()
+    rates = rates.cpu().tolist()
+    ms_per_step = elapsed / a.steps * 1e3
+
+    extras = {
+        "mxfp8_tflops_aggregate": round(rates[1], 1),
+        "hbm_read_tbps_per_gpu": round(rates[2] / world, 3),
+        "hbm_write_tbps_per_gpu": round(rates[3] / world, 3),
+        "hbm_copy_tbps_per_gpu": round(rates[4] / world, 3),
+        "hbm_triad_tbps_per_gpu": round(rates[5] / world, 3),
+        "memtest_tbps_per_gpu": round(rates[6] / world, 3),
+        "memtest_errors": int(errs_t.item()),
+        "bf16_tflops_per_gpu": round(rates[0] / world, 1),
+        "mxfp8_tflops_per_gpu": round(rates[1] / world, 1),
+        "phase_ms_max_over_ranks": {p: round(ph_max[k].item(), 3) for k, p in enumerate(phases)},
+    }
+    if world > 1:
+        for k, op in ((7, "all_reduce"), (8, "all_gather"), (9, "all_to_all")):
+            alg = COLL_BYTES / (ph_max[k].item() * 1e-3) / 1e9
+            extras[f"rccl_{op}_busbw_gbps"] = round(alg * busbw_factor(op, world), 1)
+    if exporter is not None and scrape_ms:
+        q = statistics.quantiles(scrape_ms, n=100) if len(scrape_ms) >= 2 else [scrape_ms[0]] * 99
+        extras.update({
+            "scrape_p50_ms": round(statistics.median(scrape_ms), 3),
+            "scrape_p99_ms": round(q[98], 3),
+            "scrape_bytes": scrape_bytes,
+            "scrapes": len(scrape_ms),
+            "exporter_cpu_percent_of_one_core": round(100.0 * (cpu1 - cpu0) / elapsed, 2),
+            "exporter_rss_kb": exporter.rss_kb(),
+            "exporter_interval_ms": 1000,
+        })
+    if extras["memtest_errors"]:
+        extras["FAILED"] = "memtest reported errors"
+    return {
+        "metric": "diag_mfma_bf16_gemm_tflops",
+        "value": round(rates[0], 1),
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic (random normal operands, random-init buffers)",
+        "config": {
+            "model": "gpumon diag suite: hbm stream 4GiB + memtest 4GiB + mfma gemm bf16/mxfp8 8192^3 + rccl 1GiB + exporter scrape @1s",
+            "global_batch": G * world,
+            "seq_len": D,
+            "parallelism": f"dp{world}",
+        },
+        "extras": extras,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,585 @@
+// gpumon-diag — active diagnostics for MI355X nodes (the `dcgmi diag` role; the
+// reference itself ships no active test, only the passive health watches of
+// bindings/go/dcgm/health.go:55-119).
+//
+//   gpumon-diag info                       HIP-side device facts
+//   gpumon-diag hbm    [-g GPU] [--bytes N] [--iters N] [--kernel NAME|all] [--min-tbps X]
+//   gpumon-diag memtest[-g GPU] [--bytes N | --fraction F] [--patterns a,b] [--passes N]
+//   gpumon-diag mfma   [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]
+//   gpumon-diag gemm   [-g GPU] [--dtype bf16|mxfp8|fp8] [--m M --n N --k K] [--seconds S] [--no-telemetry]
+//   gpumon-diag rccl   [--gpus 0,1,..] [--ops a,b] [--min-bytes N] [--max-bytes N] [--scaling]
+//   gpumon-diag p2p    [--gpus 0,1,..] [--bytes N]
+//   gpumon-diag run -r 1|2|3 [-g GPU]      graded suites: quick / medium / long
+// Every command takes --json.  Exit status: 0 pass, 1 a test failed, 2 usage / setup error.
+#include <unistd.h>
+
+#include <strings.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <map>
+#include <thread>
+
+#include "../diag/gpumon_diag.h"
+#include "cli_common.h"
+
+namespace {
+
+struct Args {
+  std::map<std::string, std::string> kv;
+  bool has(const std::string& k) const { return kv.count(k) != 0; }
+  std::string str(const std::string& k, const std::string& d = "") const {
+    auto it = kv.find(k);
+    return it == kv.end() ? d : it->second;
+  }
+  double num(const std::string& k, double d) const { return has(k) ? atof(str(k).c_str()) : d; }
+  uint64_t size(const std::string& k, uint64_t d) const {
+    if (!has(k)) return d;
+    std::string s = str(k);
+    double v = atof(s.c_str());
+    char u = s.empty() ? 0 : (char)toupper(s.back());
+    if (u == 'K') v *= 1ull << 10;
+    else if (u == 'M') v *= 1ull << 20;
+    else if (u == 'G') v *= 1ull << 30;
+    else if (u == 'T') v *= 1ull << 40;
+    return (uint64_t)v;
+  }
+};
+
+const char* kFlagsWithValue[] = {"-g", "--bytes", "--iters", "--kernel", "--min-tbps", "--fraction", "--patterns", "--passes",
+                                 "--dtype", "--seconds", "--m", "--n", "--k", "--gpus", "--ops", "--min-bytes",
+                                 "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor"};
+
+bool parse(const std::vector<std::string>& in, Args* a) {
+  for (size_t i = 0; i < in.size(); i++) {
+    bool takes = false;
+    for (const char* f : kFlagsWithValue) takes = takes || in[i] == f;
+    if (takes) {
+      if (i + 1 >= in.size()) {
+        fprintf(stderr, "missing value for %s\n", in[i].c_str());
+        return false;
+      }
+      a->kv[in[i]] = in[i + 1];
+      i++;
+    } else if (in[i].rfind("-", 0) == 0) {
+      a->kv[in[i]] = "1";
+    } else {
+      fprintf(stderr, "unexpected argument %s\n", in[i].c_str());
+      return false;
+    }
+  }
+  return true;
+}
+
+std::vector<std::string> csv(const std::string& s) {
+  std::vector<std::string> out;
+  size_t p = 0;
+  while (p <= s.size()) {
+    size_t c = s.find(',', p);
+    if (c == std::string::npos) c = s.size();
+    if (c > p) out.push_back(s.substr(p, c - p));
+    p = c + 1;
+  }
+  return out;
+}
+
+// Collected output: a text report and a JSON document built side by side.
+struct Report {
+  bool json = false;
+  bool failed = false;
+  std::string js;  // comma-joined members of the top-level object
+  void text(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+    if (json) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vprintf(fmt, ap);
+    va_end(ap);
+    fflush(stdout);
+  }
+  void member(const std::string& key, const std::string& value) {
+    if (!js.empty()) js += ",";
+    js += "\"" + key + "\":" + value;
+  }
+  void fail(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+    failed = true;
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "FAIL: ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+  }
+  int finish() {
+    if (json) printf("{%s,\"result\":\"%s\"}\n", js.c_str(), failed ? "fail" : "pass");
+    else printf("\nResult: %s\n", failed ? "FAIL" : "PASS");
+    return failed ? 1 : 0;
+  }
+};
+
+std::string jnum(double v) {
+  if (std::isnan(v) || std::isinf(v)) return "null";
+  char b[64];
+  snprintf(b, sizeof b, "%.6g", v);
+  return b;
+}
+std::string jstr(const std::string& s) {
+  std::string o = "\"";
+  for (char c : s) {
+    if (c == '"' || c == '\\') o += '\\';
+    o += c;
+  }
+  return o + "\"";
+}
+
+#define DIAG_CALL(rep, expr)                                                        \
+  do {                                                                              \
+    int _rc = (expr);                                                               \
+    if (_rc != GMD_OK) {                                                            \
+      fprintf(stderr, "error: %s -> %d: %s\n", #expr, _rc, gmd_last_error());       \
+      return 2;                                                                     \
+    }                                                                               \
+  } while (0)
+
+const char* kStreamNames[] = {"copy", "scale", "add", "triad", "read", "write"};
+const char* kDtypeNames[] = {"bf16", "fp8", "f32", "mxfp8"};
+struct PatName {
+  const char* name;
+  uint32_t bit;
+};
+const PatName kPatterns[] = {{"walking_ones", GMD_PAT_WALKING_ONES}, {"walking_zeros", GMD_PAT_WALKING_ZEROS},
+                             {"address", GMD_PAT_ADDRESS},           {"checkerboard", GMD_PAT_CHECKERBOARD},
+                             {"inv_checkerboard", GMD_PAT_INV_CHECKERBOARD}, {"random", GMD_PAT_RANDOM},
+                             {"modulo_20", GMD_PAT_MODULO_20}};
+
+int dtype_of(const std::string& s) {
+  for (int i = 0; i < 4; i++)
+    if (s == kDtypeNames[i]) return i;
+  return -1;
+}
+
+// ------------------------------------------------------------------ commands --
+int cmd_info(const Args& a, Report& r) {
+  int n = gmd_device_count();
+  if (n <= 0) {
+    fprintf(stderr, "error: no HIP device: %s\n", gmd_last_error());
+    return 2;
+  }
+  std::string arr = "[";
+  for (int i = 0; i < n; i++) {
+    gmd_device_info_t d;
+    DIAG_CALL(r, gmd_device_info(i, &d));
+    r.text("GPU %d: %s (%s) %s  CUs %d  %d MHz  HBM %.1f GiB (%.1f free)  L2 %d KiB  LDS/CU %d KiB\n", i, d.name, d.gcn_arch,
+           d.pci_bdf, d.compute_units, d.clock_mhz, d.total_mem / 1073741824.0, d.free_mem / 1073741824.0,
+           d.l2_bytes >> 10, d.lds_per_cu >> 10);
+    arr += std::string(i ? "," : "") + "{\"gpu\":" + std::to_string(i) + ",\"name\":" + jstr(d.name) + ",\"arch\":" +
+           jstr(d.gcn_arch) + ",\"bdf\":" + jstr(d.pci_bdf) + ",\"cus\":" + std::to_string(d.compute_units) +
+           ",\"total_mem\":" + std::to_string(d.total_mem) + ",\"free_mem\":" + std::to_string(d.free_mem) + "}";
+  }
+  r.member("devices", arr + "]");
+  return 0;
+}
+
+int cmd_hbm(const Args& a, Report& r) {
+  const int gpu = (int)a.num("-g", 0);
+  const uint64_t bytes = a.size("--bytes", 4ull << 30);
+  const int iters = (int)a.num("--iters", 10);
+  const std::string which = a.str("--kernel", "all");
+  const double floor_tbps = a.num("--min-tbps", 0);
+  r.text("HBM stream on GPU %d, %.1f GiB per buffer, %d iterations\n  %-8s %10s %10s %8s\n", gpu, bytes / 1073741824.0, iters,
+         "kernel", "best TB/s", "median", "check");
+  std::string obj = "{";
+  bool any = false;
+  for (int k = 0; k < GMD_STREAM_KERNELS; k++) {
+    if (which != "all" && which != kStreamNames[k]) continue;
+    gmd_stream_result_t s;
+    DIAG_CALL(r, gmd_hbm_stream(gpu, k, bytes, iters, 2, &s));
+    r.text("  %-8s %10.3f %10.3f %8s\n", kStreamNames[k], s.tbps_best, s.tbps_median, s.verified ? "ok" : "WRONG");
+    obj += std::string(any ? "," : "") + "\"" + kStreamNames[k] + "\":{\"tbps_best\":" + jnum(s.tbps_best) +
+           ",\"tbps_median\":" + jnum(s.tbps_median) + ",\"verified\":" + (s.verified ? "true" : "false") + "}";
+    any = true;
+    if (!s.verified) r.fail("stream %s produced wrong data", kStreamNames[k]);
+    if (floor_tbps > 0 && s.tbps_best < floor_tbps) r.fail("stream %s %.3f TB/s is under the %.3f TB/s floor", kStreamNames[k], s.tbps_best, floor_tbps);
+  }
+  if (!any) {
+    fprintf(stderr, "unknown kernel %s\n", which.c_str());
+    return 2;
+  }
+  r.member("hbm_stream", obj + "}");
+  return 0;
+}
+
+void progress_cb(double f, const char* what, void* user) {
+  if (*(bool*)user) return;
+  fprintf(stderr, "\r  %5.1f %%  %-24s", f * 100, what);
+  if (f >= 1.0) fprintf(stderr, "\n");
+}
+
+int cmd_memtest(const Args& a, Report& r) {
+  const int gpu = (int)a.num("-g", 0);
+  gmd_memtest_config_t c;
+  memset(&c, 0, sizeof c);
+  c.bytes = a.size("--bytes", 0);
+  c.fraction = a.num("--fraction", 0.90);
+  c.chunk_bytes = a.size("--chunk", 0);
+  c.passes = (uint32_t)a.num("--passes", 1);
+  if (a.has("--patterns"))
+    for (auto& p : csv(a.str("--patterns"))) {
+      bool ok = false;
+      for (auto& pn : kPatterns)
+        if (p == pn.name) c.patterns |= pn.bit, ok = true;
+      if (!ok) {
+        fprintf(stderr, "unknown pattern %s\n", p.c_str());
+        return 2;
+      }
+    }
+  bool quiet = r.json || !isatty(2);
+  c.progress = progress_cb;
+  c.progress_user = &quiet;
+  gmd_memtest_result_t m;
+  DIAG_CALL(r, gmd_memtest(gpu, &c, &m));
+  r.text("memtest on GPU %d: %.1f GiB in %u chunks, %u patterns, %.2f s\n  write %.2f TB/s  verify %.2f TB/s  errors %llu\n", gpu,
+         m.bytes_tested / 1073741824.0, m.chunks, m.patterns_run, m.seconds, m.write_tbps, m.verify_tbps,
+         (unsigned long long)m.errors);
+  std::string log = "[";
+  for (uint32_t i = 0; i < m.logged; i++) {
+    r.text("  offset 0x%llx pattern 0x%x expected %016llx got %016llx\n", (unsigned long long)m.log[i].byte_offset,
+           m.log[i].pattern, (unsigned long long)m.log[i].expected, (unsigned long long)m.log[i].actual);
+    log += std::string(i ? "," : "") + "{\"offset\":" + std::to_string(m.log[i].byte_offset) + ",\"pattern\":" +
+           std::to_string(m.log[i].pattern) + "}";
+  }
+  r.member("memtest", "{\"bytes_tested\":" + std::to_string(m.bytes_tested) + ",\"errors\":" + std::to_string(m.errors) +
+                          ",\"patterns\":" + std::to_string(m.patterns_run) + ",\"write_tbps\":" + jnum(m.write_tbps) +
+                          ",\"verify_tbps\":" + jnum(m.verify_tbps) + ",\"seconds\":" + jnum(m.seconds) + ",\"log\":" + log + "]}");
+  if (m.errors) r.fail("memtest found %llu bad words", (unsigned long long)m.errors);
+  return 0;
+}
+
+int cmd_mfma(const Args& a, Report& r) {
+  const int gpu = (int)a.num("-g", 0);
+  const std::string which = a.str("--dtype", "all");
+  const double secs = a.num("--seconds", 1.0);
+  r.text("MFMA pipe peak on GPU %d (%.1f s per dtype)\n  %-6s %12s %12s %10s\n", gpu, secs, "dtype", "TFLOP/s", "best", "MHz");
+  std::string obj = "{";
+  bool any = false;
+  for (int dt : {GMD_DT_BF16, GMD_DT_FP8, GMD_DT_MXFP8, GMD_DT_F32}) {
+    if (which != "all" && which != kDtypeNames[dt]) continue;
+    gmd_mfma_result_t m;
+    DIAG_CALL(r, gmd_mfma_peak(gpu, dt, secs, &m));
+    r.text("  %-6s %12.1f %12.1f %10.0f\n", kDtypeNames[dt], m.tflops, m.tflops_best, m.clock_mhz_est);
+    obj += std::string(any ? "," : "") + "\"" + kDtypeNames[dt] + "\":{\"tflops\":" + jnum(m.tflops) + ",\"tflops_best\":" +
+           jnum(m.tflops_best) + ",\"clock_mhz\":" + jnum(m.clock_mhz_est) + "}";
+    any = true;
+    if (m.verified < 0) r.fail("MFMA %s pipe produced wrong results", kDtypeNames[dt]);
+  }
+  if (!any) return 2;
+  r.member("mfma_peak", obj + "}");
+  return 0;
+}
+
+// Engine-side telemetry of the GPU under stress: power / temperature / clocks at 100 ms.
+struct Soak {
+  bool on = false;
+  uint32_t gpu = 0;
+  int64_t t0 = 0;
+  gm_group_t group = 0;
+  gm_field_group_t fg = 0;
+  bool start(int hip_dev) {
+    gmd_device_info_t d;
+    if (gmd_device_info(hip_dev, &d) != GMD_OK) return false;
+    gm_init_params_t p;
+    memset(&p, 0, sizeof p);
+    p.version = GM_INIT_PARAMS_VERSION;
+    p.mode = GM_MODE_EMBEDDED;
+    if (gm_init(&p) != GM_ST_OK) return false;
+    uint32_t n = 0;
+    gm_device_count(&n);
+    bool found = false;
+    for (uint32_t i = 0; i < n && !found; i++) {
+      gm_device_attributes_t at;
+      memset(&at, 0, sizeof at);
+      at.version = GM_DEVICE_ATTRIBUTES_VERSION;
+      if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, d.pci_bdf) == 0) gpu = i, found = true;
+    }
+    if (!found) {
+      gm_shutdown();
+      return false;
+    }
+    uint16_t ids[] = {GM_FI_POWER_USAGE, GM_FI_GPU_TEMP, GM_FI_MEM_TEMP, GM_FI_GFX_CLOCK, GM_FI_MEM_CLOCK, GM_FI_GFX_UTIL};
+    gm_group_create("diag-soak", &group);
+    gm_group_add_device(group, gpu);
+    gm_field_group_create(ids, 6, "diag-soak", &fg);
+    gm_watch_fields(group, fg, 100000, 600.0, 0);
+    gm_update_all_fields(1);
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    t0 = (int64_t)ts.tv_sec * 1000000 + ts.tv_nsec / 1000;
+    on = true;
+    return true;
+  }
+  std::string summarize(Report& r) {
+    if (!on) return "null";
+    struct F {
+      uint16_t id;
+      const char* name;
+      const char* unit;
+    } fs[] = {{GM_FI_POWER_USAGE, "power", "W"},     {GM_FI_GPU_TEMP, "gpu_temp", "C"},   {GM_FI_MEM_TEMP, "hbm_temp", "C"},
+              {GM_FI_GFX_CLOCK, "gfx_clock", "MHz"}, {GM_FI_MEM_CLOCK, "mem_clock", "MHz"}, {GM_FI_GFX_UTIL, "gfx_util", "%"}};
+    std::string obj = "{";
+    r.text("  telemetry during the run (100 ms samples):\n");
+    bool first = true;
+    for (auto& f : fs) {
+      std::vector<gm_value_t> v(8192);
+      int n = (int)v.size();
+      if (gm_values_since(gpu, f.id, t0, v.data(), &n) != GM_ST_OK) continue;
+      double lo = 1e300, hi = -1e300, sum = 0;
+      int cnt = 0;
+      for (int i = 0; i < n; i++) {
+        if (v[i].status != GM_VS_OK) continue;
+        double x = v[i].type == GM_FT_DOUBLE ? v[i].v.dbl : (double)v[i].v.i64;
+        lo = std::min(lo, x), hi = std::max(hi, x), sum += x, cnt++;
+      }
+      if (!cnt) continue;
+      r.text("    %-10s min %8.1f  avg %8.1f  max %8.1f %s  (%d samples)\n", f.name, lo, sum / cnt, hi, f.unit, cnt);
+      obj += std::string(first ? "" : ",") + "\"" + f.name + "\":{\"min\":" + jnum(lo) + ",\"avg\":" + jnum(sum / cnt) +
+             ",\"max\":" + jnum(hi) + ",\"samples\":" + std::to_string(cnt) + "}";
+      first = false;
+    }
+    return obj + "}";
+  }
+  void stop() {
+    if (on) gm_shutdown();
+    on = false;
+  }
+};
+
+int cmd_gemm(const Args& a, Report& r) {
+  const int gpu = (int)a.num("-g", 0);
+  const std::string which = a.str("--dtype", "bf16,mxfp8");
+  const int m = (int)a.num("--m", 8192), n = (int)a.num("--n", 8192), k = (int)a.num("--k", 8192);
+  const double secs = a.num("--seconds", 5.0), floor_tf = a.num("--min-tflops", 0);
+  Soak soak;
+  if (!a.has("--no-telemetry") && !soak.start(gpu)) fprintf(stderr, "note: engine telemetry unavailable; running without it\n");
+  std::string obj = "{";
+  bool any = false;
+  for (auto& name : csv(which)) {
+    int dt = dtype_of(name);
+    if (dt < 0 || dt == GMD_DT_F32) {
+      fprintf(stderr, "unknown GEMM dtype %s\n", name.c_str());
+      soak.stop();
+      return 2;
+    }
+    gmd_mfma_result_t g;
+    int rc = gmd_gemm_stress(gpu, dt, m, n, k, secs, 1, &g);
+    if (rc != GMD_OK && rc != GMD_ERR_VERIFY) {
+      fprintf(stderr, "error: gemm stress -> %d: %s\n", rc, gmd_last_error());
+      soak.stop();
+      return 2;
+    }
+    r.text("GEMM stress %s %dx%dx%d on GPU %d: %.1f TFLOP/s (best %.1f), %llu launches in %.1f s, sdc mismatches %llu, check %s\n",
+           name.c_str(), m, n, k, gpu, g.tflops, g.tflops_best, (unsigned long long)g.launches, g.seconds,
+           (unsigned long long)g.sdc_mismatches, g.verified > 0 ? "ok" : g.verified < 0 ? "WRONG" : "skipped");
+    obj += std::string(any ? "," : "") + "\"" + name + "\":{\"tflops\":" + jnum(g.tflops) + ",\"tflops_best\":" +
+           jnum(g.tflops_best) + ",\"launches\":" + std::to_string(g.launches) + ",\"sdc_mismatches\":" +
+           std::to_string(g.sdc_mismatches) + ",\"max_rel_err\":" + jnum(g.max_rel_err) + ",\"verified\":" +
+           std::to_string(g.verified) + "}";
+    any = true;
+    if (g.verified < 0) r.fail("GEMM %s result does not match the reference", name.c_str());
+    if (g.sdc_mismatches) r.fail("GEMM %s: %llu launches changed their checksum (silent data corruption)", name.c_str(), (unsigned long long)g.sdc_mismatches);
+    if (floor_tf > 0 && g.tflops < floor_tf) r.fail("GEMM %s %.1f TFLOP/s is under the %.1f floor", name.c_str(), g.tflops, floor_tf);
+  }
+  r.member("gemm_stress", obj + "}");
+  r.member("telemetry", soak.summarize(r));
+  soak.stop();
+  return 0;
+}
+
+bool parse_gpus(const Args& a, std::vector<int>* ids) {
+  if (!a.has("--gpus")) return true;
+  for (auto& s : csv(a.str("--gpus"))) ids->push_back(atoi(s.c_str()));
+  return !ids->empty();
+}
+
+int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, std::string* js) {
+  gmd_rccl_config_t c;
+  memset(&c, 0, sizeof c);
+  c.ndev = (int)ids.size();
+  c.devices = ids.empty() ? nullptr : ids.data();
+  c.min_bytes = a.size("--min-bytes", 8);
+  c.max_bytes = a.size("--max-bytes", 1ull << 30);
+  c.factor = (int)a.num("--factor", 4);
+  c.iters = (int)a.num("--iters", 0);
+  c.verify = a.has("--no-verify") ? 0 : 1;
+  if (a.has("--ops"))
+    for (auto& o : csv(a.str("--ops"))) {
+      bool ok = false;
+      for (int i = 0; i < GMD_COLL_COUNT; i++)
+        if (o == gmd_collective_name(i)) c.ops_mask |= 1u << i, ok = true;
+      if (!ok) {
+        fprintf(stderr, "unknown collective %s\n", o.c_str());
+        return 2;
+      }
+    }
+  std::vector<gmd_rccl_point_t> pts(512);
+  int n = (int)pts.size();
+  DIAG_CALL(r, gmd_rccl_sweep(&c, pts.data(), &n));
+  double peak[GMD_COLL_COUNT] = {0};
+  int w = n ? pts[0].ndev : 0;
+  r.text("# RCCL sweep on %d GPU%s\n# %-15s%14s%7s%12s%13s%13s  check\n", w, w == 1 ? "" : "s", "op", "bytes", "iters", "time(us)",
+         "algbw(GB/s)", "busbw(GB/s)");
+  *js += "{\"gpus\":" + std::to_string(w) + ",\"points\":[";
+  for (int i = 0; i < n; i++) {
+    auto& p = pts[i];
+    r.text("  %-15s%14llu%7d%12.1f%13.2f%13.2f  %s\n", gmd_collective_name(p.op), (unsigned long long)p.bytes, p.iters, p.time_us,
+           p.algbw_gbps, p.busbw_gbps, p.verified > 0 ? "ok" : p.verified < 0 ? "MISMATCH" : "-");
+    peak[p.op] = std::max(peak[p.op], p.busbw_gbps);
+    *js += std::string(i ? "," : "") + "{\"op\":" + jstr(gmd_collective_name(p.op)) + ",\"bytes\":" + std::to_string(p.bytes) +
+           ",\"time_us\":" + jnum(p.time_us) + ",\"algbw_gbps\":" + jnum(p.algbw_gbps) + ",\"busbw_gbps\":" + jnum(p.busbw_gbps) +
+           ",\"verified\":" + std::to_string(p.verified) + "}";
+    if (p.verified < 0) r.fail("%s of %llu bytes on %d GPUs returned wrong data", gmd_collective_name(p.op), (unsigned long long)p.bytes, w);
+  }
+  *js += "],\"peak_busbw_gbps\":{";
+  r.text("# peak busbw (GB/s):");
+  bool first = true;
+  for (int i = 0; i < GMD_COLL_COUNT; i++) {
+    if (peak[i] <= 0) continue;
+    r.text("  %s=%.1f", gmd_collective_name(i), peak[i]);
+    *js += std::string(first ? "" : ",") + "\"" + gmd_collective_name(i) + "\":" + jnum(peak[i]);
+    first = false;
+  }
+  r.text("\n");
+  *js += "}}";
+  return 0;
+}
+
+int cmd_rccl(const Args& a, Report& r) {
+  std::vector<int> ids;
+  if (!parse_gpus(a, &ids)) return 2;
+  if (!a.has("--scaling")) {
+    std::string js;
+    int rc = run_sweep(a, r, ids, &js);
+    if (rc) return rc;
+    r.member("rccl", js);
+    return 0;
+  }
+  // 1 / 2 / 4 / 8 ... GPUs: the scaling series.
+  int visible = gmd_device_count();
+  if (ids.empty())
+    for (int i = 0; i < visible; i++) ids.push_back(i);
+  std::string arr = "[";
+  for (size_t w = 1; w <= ids.size(); w *= 2) {
+    std::vector<int> sub(ids.begin(), ids.begin() + w);
+    std::string js;
+    int rc = run_sweep(a, r, sub, &js);
+    if (rc) return rc;
+    arr += std::string(w > 1 ? "," : "") + js;
+  }
+  r.member("rccl_scaling", arr + "]");
+  return 0;
+}
+
+int cmd_p2p(const Args& a, Report& r) {
+  std::vector<int> ids;
+  if (!parse_gpus(a, &ids)) return 2;
+  int w = ids.empty() ? gmd_device_count() : (int)ids.size();
+  if (w <= 0) return 2;
+  std::vector<double> m((size_t)w * w);
+  DIAG_CALL(r, gmd_p2p_matrix(w, ids.empty() ? nullptr : ids.data(), a.size("--bytes", 256ull << 20), (int)a.num("--iters", 5), m.data()));
+  r.text("# peer copy bandwidth, GB/s (row = source GPU)\n");
+  std::string js = "[";
+  double lo = 1e300, hi = 0;
+  for (int i = 0; i < w; i++) {
+    js += std::string(i ? "," : "") + "[";
+    r.text("  ");
+    for (int j = 0; j < w; j++) {
+      double v = m[(size_t)i * w + j];
+      r.text("%8.1f", v);
+      js += std::string(j ? "," : "") + jnum(v);
+      if (i != j && v >= 0) lo = std::min(lo, v), hi = std::max(hi, v);
+      if (i != j && v < 0) r.fail("GPU %d cannot access GPU %d as a peer", i, j);
+    }
+    r.text("\n");
+    js += "]";
+  }
+  r.member("p2p_gbps", js + "]");
+  // One link well below its siblings is the signature of a degraded xGMI lane.
+  if (w > 1 && hi > 0 && lo < 0.6 * hi) r.fail("slowest pair %.1f GB/s is under 60 %% of the fastest (%.1f GB/s)", lo, hi);
+  return 0;
+}
+
+int cmd_run(const Args& a, Report& r) {
+  const int level = (int)a.num("-r", 1);
+  if (level < 1 || level > 3) {
+    fprintf(stderr, "-r takes 1, 2 or 3\n");
+    return 2;
+  }
+  Args sub = a;
+  int rc;
+  if ((rc = cmd_info(sub, r))) return rc;
+  // level 1 (quick, seconds): short stream + 1 GiB memtest.  level 2 adds the matrix pipes and a 5 s
+  // GEMM stress.  level 3 sweeps 90 % of HBM, soaks 60 s and exercises the fabric.
+  sub.kv["--bytes"] = level == 1 ? "1G" : "4G";
+  sub.kv["--iters"] = level == 1 ? "5" : "20";
+  if ((rc = cmd_hbm(sub, r))) return rc;
+  if (level < 3) sub.kv["--bytes"] = level == 1 ? "1G" : "16G";
+  else sub.kv.erase("--bytes");
+  if ((rc = cmd_memtest(sub, r))) return rc;
+  if (level >= 2) {
+    sub.kv["--seconds"] = "1";
+    if ((rc = cmd_mfma(sub, r))) return rc;
+    sub.kv["--seconds"] = level == 2 ? "5" : "60";
+    sub.kv.erase("--dtype");
+    if ((rc = cmd_gemm(sub, r))) return rc;
+  }
+  if (level >= 3) {
+    sub.kv.erase("--bytes");
+    sub.kv.erase("--iters");
+    sub.kv["--scaling"] = "1";
+    if ((rc = cmd_rccl(sub, r))) return rc;
+    if (gmd_device_count() > 1 && (rc = cmd_p2p(sub, r))) return rc;
+  }
+  return 0;
+}
+
+void usage() {
+  fprintf(stderr,
+          "usage: gpumon-diag <info|hbm|memtest|mfma|gemm|rccl|p2p|run> [options] [--json]\n"
+          "  hbm     [-g GPU] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
+          "  memtest [-g GPU] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N]\n"
+          "  mfma    [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
+          "  gemm    [-g GPU] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--min-tflops X] [--no-telemetry]\n"
+          "  rccl    [--gpus LIST] [--ops LIST] [--min-bytes N] [--max-bytes N] [--factor N] [--iters N] [--scaling] [--no-verify]\n"
+          "  p2p     [--gpus LIST] [--bytes N] [--iters N]\n"
+          "  run     -r 1|2|3 [-g GPU]\n");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    usage();
+    return 2;
+  }
+  std::string cmd = argv[1];
+  Args a;
+  if (!parse(std::vector<std::string>(argv + 2, argv + argc), &a)) {
+    usage();
+    return 2;
+  }
+  Report r;
+  r.json = a.has("--json");
+  int rc;
+  if (cmd == "info") rc = cmd_info(a, r);
+  else if (cmd == "hbm") rc = cmd_hbm(a, r);
+  else if (cmd == "memtest") rc = cmd_memtest(a, r);
+  else if (cmd == "mfma") rc = cmd_mfma(a, r);
+  else if (cmd == "gemm") rc = cmd_gemm(a, r);
+  else if (cmd == "rccl") rc = cmd_rccl(a, r);
+  else if (cmd == "p2p") rc = cmd_p2p(a, r);
+  else if (cmd == "run") rc = cmd_run(a, r);
+  else {
+    usage();
+    return 2;
+  }
+  if (rc) return rc;
+  return r.finish();
+}

@@ -417,6 +417,16 @@ class AmdSmiBackend : public Backend {
       memset(&a, 0, sizeof a);
       if (api_.amdsmi_get_gpu_asic_info(d.h, &a) == AMDSMI_STATUS_SUCCESS) {
         s.name = trim(a.market_name);
+        // Without libdrm's amdgpu.ids the library only knows the generic family
+        // string; the Instinct PCI device ids are few enough to name here.
+        if (s.name.empty() || s.name == "AMD Radeon Graphics") {
+          static const struct { uint64_t id; const char* name; } kInstinct[] = {
+              {0x75a3, "AMD Instinct MI355X"}, {0x75a0, "AMD Instinct MI350X"}, {0x74a5, "AMD Instinct MI325X"},
+              {0x74a1, "AMD Instinct MI300X"}, {0x74a9, "AMD Instinct MI300X HF"}, {0x74a0, "AMD Instinct MI300A"},
+              {0x740f, "AMD Instinct MI210"},  {0x740c, "AMD Instinct MI250X"},   {0x7408, "AMD Instinct MI250X"}};
+          for (auto& k : kInstinct)
+            if (k.id == a.device_id) s.name = k.name;
+        }
         s.brand = trim(a.vendor_name);
         s.serial = trim(a.asic_serial);
         if (valid(a.num_of_compute_units)) s.num_cu = a.num_of_compute_units;
@@ -729,14 +739,18 @@ class AmdSmiBackend : public Backend {
     }
     uint64_t used = 0;
     amdsmi_status_t rc = api_.amdsmi_get_gpu_memory_usage(d.h, AMDSMI_MEM_TYPE_VRAM, &used);
+    // A loaded driver always holds some VRAM itself, so exactly 0 is not a reading:
+    // it is what the library returns where the kernel's mem_info_vram_used counter is
+    // not exposed (seen on virtualised hosts).  Report "not supported", not "0 MiB used".
+    if (rc == AMDSMI_STATUS_SUCCESS && used == 0 &&
+        access(("/sys/bus/pci/devices/" + d.st.pci_bdf + "/mem_info_vram_used").c_str(), R_OK) != 0)
+      rc = AMDSMI_STATUS_NOT_SUPPORTED;
     if (rc == AMDSMI_STATUS_SUCCESS) {
       int64_t used_mib = (int64_t)(used >> 20);
       out->set_i(GM_FI_VRAM_USED, used_mib);
-      if (d.st.vram_total_mib >= 0) {
-        out->set_i(GM_FI_VRAM_TOTAL, d.st.vram_total_mib);
-        out->set_i(GM_FI_VRAM_FREE, d.st.vram_total_mib - used_mib);
-      }
+      if (d.st.vram_total_mib >= 0) out->set_i(GM_FI_VRAM_FREE, d.st.vram_total_mib - used_mib);
     }
+    if (d.st.vram_total_mib >= 0) out->set_i(GM_FI_VRAM_TOTAL, d.st.vram_total_mib);  // known even when usage is not
     uint64_t v = 0;
     amdsmi_status_t r2 = api_.amdsmi_get_gpu_memory_usage(d.h, AMDSMI_MEM_TYPE_VIS_VRAM, &v);
     if (r2 == AMDSMI_STATUS_SUCCESS) out->set_i(GM_FI_DEV_VIS_VRAM_USED, (int64_t)(v >> 20));

@@ -29,7 +29,8 @@ enum {
   GMD_ERR_HIP = -2,      /* a HIP call failed; see gmd_last_error() */
   GMD_ERR_NO_DEVICE = -3,
   GMD_ERR_NOMEM = -4,
-  GMD_ERR_VERIFY = -5    /* the kernel ran but its result is wrong */
+  GMD_ERR_VERIFY = -5,   /* the kernel ran but its result is wrong */
+  GMD_ERR_UNSUPPORTED = -6 /* a run-time dependency (librccl) is missing */
 };
 
 GMD_API const char* gmd_last_error(void);
@@ -67,14 +68,17 @@ typedef struct {
  * 256 MiB Infinity Cache must not hold the working set). */
 GMD_API int gmd_hbm_stream(int device, int kernel, uint64_t bytes_per_buffer, int iters, int nontemporal,
                            gmd_stream_result_t* out);
-/* One launch on caller buffers (float elements); for numerics tests. */
+/* One launch on caller buffers (float elements, 16-byte aligned, count a multiple of 4).
+ * READ: `c`, when not NULL, receives one partial sum per workgroup and must hold
+ * GMD_STREAM_SINK_FLOATS floats (the launch is then fully asynchronous). */
+#define GMD_STREAM_SINK_FLOATS 32768
 GMD_API int gmd_hbm_stream_launch(int kernel, void* a, void* b, void* c, float scalar, uint64_t n_floats,
                                   int nontemporal, void* hip_stream);
 
 /* --------------------------------------------------------------- memtest -- */
 #define GMD_PAT_WALKING_ONES (1u << 0)
 #define GMD_PAT_WALKING_ZEROS (1u << 1)
-#define GMD_PAT_ADDRESS (1u << 2)      /* every word holds its own index */
+#define GMD_PAT_ADDRESS (1u << 2)      /* every word holds its own byte offset in the region */
 #define GMD_PAT_CHECKERBOARD (1u << 3) /* 0xAAAA... */
 #define GMD_PAT_INV_CHECKERBOARD (1u << 4)
 #define GMD_PAT_RANDOM (1u << 5)       /* counter-based hash of (index, seed) */
@@ -149,6 +153,52 @@ GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double s
 /* One GEMM on caller memory.  A: [M,K] row-major, B: [N,K] row-major (i.e. B^T), C: [M,N] row-major.
  * bf16: A,B bf16, C bf16.  fp8: A,B OCP e4m3, C bf16.  M,N multiples of 256; K multiple of 64 (bf16) / 128 (fp8). */
 GMD_API int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream);
+
+/* ---------------------------------------------------------- interconnect -- */
+/* Single-process RCCL sweep: one communicator per listed GPU (ncclCommInitAll),
+ * collectives issued as one group per iteration.  librccl is loaded at run time.
+ * payload bytes: all_reduce / broadcast = the buffer; all_gather / reduce_scatter =
+ * the gathered (total) buffer; all_to_all = one GPU's send buffer. */
+typedef enum {
+  GMD_COLL_ALL_REDUCE = 0,
+  GMD_COLL_ALL_GATHER = 1,
+  GMD_COLL_REDUCE_SCATTER = 2,
+  GMD_COLL_ALL_TO_ALL = 3,
+  GMD_COLL_BROADCAST = 4,
+  GMD_COLL_COUNT = 5
+} gmd_collective_t;
+
+typedef struct {
+  int32_t ndev;          /* 0 = all visible GPUs */
+  const int* devices;    /* NULL = 0..ndev-1 */
+  uint32_t ops_mask;     /* bit per gmd_collective_t; 0 = all */
+  uint64_t min_bytes;    /* default 8 */
+  uint64_t max_bytes;    /* default 1 GiB */
+  int32_t factor;        /* size step, default 4 */
+  int32_t iters;         /* 0 = size dependent (50 / 20 / 8) */
+  int32_t warmup;        /* default 3 */
+  int32_t verify;        /* 1 = check every size once on patterned data */
+} gmd_rccl_config_t;
+
+typedef struct {
+  int32_t op;
+  int32_t ndev;
+  uint64_t bytes;
+  int32_t iters;
+  int32_t verified;      /* 1 ok, 0 not checked, -1 mismatch */
+  double time_us;
+  double algbw_gbps;     /* 1e9 bytes/s */
+  double busbw_gbps;
+} gmd_rccl_point_t;
+
+GMD_API const char* gmd_collective_name(int op);
+GMD_API double gmd_busbw_factor(int op, int ndev);
+/* *n: capacity of out on entry, points written on return. */
+GMD_API int gmd_rccl_sweep(const gmd_rccl_config_t* cfg, gmd_rccl_point_t* out, int* n);
+/* Pairwise copy bandwidth over the GPU fabric with peer access (hipMemcpyPeerAsync):
+ * gbps[i*ndev+j] = devices[i] -> devices[j], 0 on the diagonal, -1 where peer access
+ * is not available.  On MI355X each ordered pair is one xGMI link. */
+GMD_API int gmd_p2p_matrix(int ndev, const int* devices, uint64_t bytes, int iters, double* gbps);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(kBlock) void stream_kernel(f32x4* __restrict__ a, f
 }
 
 constexpr unsigned kMaxGrid = gmd::kCUs * 128;  // spans of >= 16 KiB; best measured point of the sweep
+static_assert(kMaxGrid <= GMD_STREAM_SINK_FLOATS, "a caller-provided READ sink must cover the grid");
 
 // Grid and span (in 16-byte elements, a multiple of one unrolled workgroup pass).
 inline void plan(uint64_t n4, unsigned* grid, uint64_t* span) {
@@ -150,12 +151,21 @@ int gmd_hbm_stream_launch(int kernel, void* a, void* b, void* c, float scalar, u
   if ((kernel == GMD_STREAM_SCALE) && (!b || !c)) return GMD_ERR_BADPARAM;
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return GMD_ERR_BADPARAM;
   hipStream_t st = (hipStream_t)hip_stream;
+  // READ leaves one partial sum per workgroup in a sink of GMD_STREAM_SINK_FLOATS floats:
+  // the caller's `c` when given (fully asynchronous), else a temporary (synchronises).
   float* sink = nullptr;
-  if (kernel == GMD_STREAM_READ) GMD_HIP(hipMalloc((void**)&sink, sizeof(float) * kMaxGrid));
+  bool own_sink = false;
+  if (kernel == GMD_STREAM_READ) {
+    sink = (float*)c;
+    if (!sink) {
+      GMD_HIP(hipMalloc((void**)&sink, sizeof(float) * kMaxGrid));
+      own_sink = true;
+    }
+  }
   if (use_nt(kernel, nontemporal)) launch<true>(kernel, (f32x4*)a, (f32x4*)b, (f32x4*)c, scalar, n_floats / 4, sink, st);
   else launch<false>(kernel, (f32x4*)a, (f32x4*)b, (f32x4*)c, scalar, n_floats / 4, sink, st);
   hipError_t e = hipGetLastError();
-  if (sink) {
+  if (own_sink) {
     (void)hipStreamSynchronize(st);
     (void)hipFree(sink);
   }

@@ -186,6 +186,67 @@ def gemm_stress(dtype="bf16", m=8192, n=8192, k=8192, seconds=2.0, verify=True, 
     return _dict(r)
 
 
+COLLECTIVES = {"all_reduce": 0, "all_gather": 1, "reduce_scatter": 2, "all_to_all": 3, "broadcast": 4}
+
+
+class RcclConfig(C.Structure):
+    _fields_ = [("ndev", C.c_int32), ("devices", C.POINTER(C.c_int)), ("ops_mask", C.c_uint32),
+                ("min_bytes", C.c_uint64), ("max_bytes", C.c_uint64), ("factor", C.c_int32), ("iters", C.c_int32),
+                ("warmup", C.c_int32), ("verify", C.c_int32)]
+
+
+class RcclPoint(C.Structure):
+    _fields_ = [("op", C.c_int32), ("ndev", C.c_int32), ("bytes", C.c_uint64), ("iters", C.c_int32),
+                ("verified", C.c_int32), ("time_us", C.c_double), ("algbw_gbps", C.c_double),
+                ("busbw_gbps", C.c_double)]
+
+
+def busbw_factor(op, ndev):
+    L = _lib()
+    L.gmd_busbw_factor.restype = C.c_double
+    L.gmd_busbw_factor.argtypes = [C.c_int, C.c_int]
+    return L.gmd_busbw_factor(COLLECTIVES[op], ndev)
+
+
+def rccl_sweep(devices=None, ops=None, min_bytes=8, max_bytes=1 << 30, factor=4, iters=0, warmup=3, verify=True):
+    """Single-process RCCL sweep over `devices` (default: all visible); list of dicts, one per (op, size)."""
+    L = _lib()
+    L.gmd_rccl_sweep.argtypes = [C.POINTER(RcclConfig), C.POINTER(RcclPoint), C.POINTER(C.c_int)]
+    cfg = RcclConfig()
+    keep = None
+    if devices:
+        keep = (C.c_int * len(devices))(*devices)
+        cfg.ndev, cfg.devices = len(devices), keep
+    for o in ops or ():
+        cfg.ops_mask |= 1 << COLLECTIVES[o]
+    cfg.min_bytes, cfg.max_bytes, cfg.factor = min_bytes, max_bytes, factor
+    cfg.iters, cfg.warmup, cfg.verify = iters, warmup, int(verify)
+    pts = (RcclPoint * 512)()
+    n = C.c_int(512)
+    rc = L.gmd_rccl_sweep(C.byref(cfg), pts, C.byref(n))
+    if rc:
+        raise DiagError(rc, "gmd_rccl_sweep")
+    names = {v: k for k, v in COLLECTIVES.items()}
+    out = []
+    for i in range(n.value):
+        d = _dict(pts[i])
+        d["op"] = names[d["op"]]
+        out.append(d)
+    return out
+
+
+def p2p_matrix(devices=None, bytes=256 << 20, iters=5):
+    L = _lib()
+    L.gmd_p2p_matrix.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+    n = len(devices) if devices else device_count()
+    arr = (C.c_int * n)(*devices) if devices else None
+    m = (C.c_double * (n * n))()
+    rc = L.gmd_p2p_matrix(n, arr, bytes, iters, m)
+    if rc:
+        raise DiagError(rc, "gmd_p2p_matrix")
+    return [[m[i * n + j] for j in range(n)] for i in range(n)]
+
+
 def gemm_launch(dtype, a_ptr, b_ptr, c_ptr, m, n, k, stream=None):
     """C[M,N] (bf16) = A[M,K] @ B[N,K]^T on caller memory."""
     rc = _lib().gmd_gemm_launch(DTYPES[dtype], a_ptr, b_ptr, c_ptr, m, n, k, stream)

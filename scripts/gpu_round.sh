@@ -1,0 +1,59 @@
+#!/bin/bash
+# One GPU-box session: GPU tests, smoke, bench, diag CLI, profiles.  Every step runs
+# under its own time limit; a step that ends with anything but 0 (ok) or 1 (an
+# ordinary test failure) ends the session, so nothing is launched after a fault,
+# an abort or a hang.
+# usage: scripts/gpu_round.sh [step ...]   (default: tests smoke bench diag)
+set -u
+cd "$(dirname "$0")/.."
+OUT=gpurun_out
+mkdir -p "$OUT"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+
+step() {  # step <name> <seconds> <cmd...>
+  local name=$1 secs=$2
+  shift 2
+  echo "=== $name ($(date +%T))"
+  timeout -k 10 "$secs" "$@" > "$OUT/$name.log" 2>&1
+  local rc=$?
+  echo "=== $name exit $rc"
+  tail -n 15 "$OUT/$name.log"
+  if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then
+    echo "stopping: $name ended with $rc"
+    exit $rc
+  fi
+}
+
+STEPS=${*:-tests smoke bench diag}
+for s in $STEPS; do
+  case $s in
+    tests) step gpu_tests 900 python -u -m pytest tests -m gpu -v --timeout 120 --timeout-method thread ;;
+    smoke) step smoke 300 python -u -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench) step bench 600 python -u bench.py --steps 50 --warmup 5 ;;
+    diag)
+      step diag_run2 600 build/bin/gpumon-diag run -r 2
+      step diag_rccl 300 build/bin/gpumon-diag rccl --max-bytes 256M --factor 16
+      ;;
+    gemmcheck) step gemm_check 600 python -u scripts/gpu_gemm_check.py ;;
+    prof)
+      # kernel trace of a short bench run; rocprofv3 wants a writable cwd-independent TMPDIR
+      export TMPDIR=/tmp
+      step prof_bench 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$PWD/$OUT/prof_bench" -o bench -- python3 bench.py --steps 5 --warmup 2 --no-exporter
+      ;;
+    pmc)
+      # One counter pass per run (rocprofv3 does not multiplex): SQ pass, L2 read pass, L2 write/hit pass.
+      export TMPDIR=/tmp
+      D="$PWD/build/bin/gpumon-diag"
+      for target in "gemm_bf16:gemm --dtype bf16 --seconds 0.05 --no-telemetry" "gemm_mxfp8:gemm --dtype mxfp8 --seconds 0.05 --no-telemetry" \
+                    "hbm:hbm --bytes 2G --iters 2" "memtest:memtest --bytes 4G --patterns random,address"; do
+        name=${target%%:*}; args=${target#*:}
+        step "pmc_sq_$name" 120 timeout -s KILL 100 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_UNALIGNED_STALL \
+          --output-format csv -d "$PWD/$OUT/pmc_sq_$name" -o p -- "$D" $args
+        step "pmc_rd_$name" 120 timeout -s KILL 100 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$PWD/$OUT/pmc_rd_$name" -o p -- "$D" $args
+        step "pmc_wr_$name" 120 timeout -s KILL 100 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$PWD/$OUT/pmc_wr_$name" -o p -- "$D" $args
+      done
+      ;;
+    *) echo "unknown step $s"; exit 2 ;;
+  esac
+done
+echo "=== session complete"

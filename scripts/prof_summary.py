@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (kernel trace and/or counter collection) into a
+small markdown report: per-kernel call counts and times, per-kernel counter sums.
+
+usage: prof_summary.py <dir-with-csv> <out.md> [title]
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name, n=72):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    name = name.split("(")[0] if len(name) > n else name
+    return name if len(name) <= n else name[: n - 3] + "..."
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    title = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(src.rstrip("/"))
+    lines = [f"# {title}", ""]
+    for path in sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)):
+        agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3  # us
+                a = agg[short(row["Kernel_Name"])]
+                a[0] += 1
+                a[1] += dur
+                a[2] = min(a[2], dur)
+                a[3] = max(a[3], dur)
+        total = sum(a[1] for a in agg.values()) or 1.0
+        lines += [f"## kernel trace ({os.path.basename(path)})", "", "| kernel | calls | total us | avg us | min us | max us | % |",
+                  "|---|---:|---:|---:|---:|---:|---:|"]
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+            lines.append(f"| `{k}` | {a[0]} | {a[1]:.1f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} | {100 * a[1] / total:.1f} |")
+        lines.append("")
+    for path in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
+        agg = defaultdict(lambda: defaultdict(float))
+        calls = defaultdict(set)
+        regs = {}
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                calls[k].add(row.get("Dispatch_Id", ""))
+                regs[k] = (row.get("VGPR_Count", "?"), row.get("Accum_VGPR_Count", "?"), row.get("SGPR_Count", "?"),
+                           row.get("LDS_Block_Size", "?"), row.get("Workgroup_Size", "?"), row.get("Grid_Size", "?"))
+        counters = sorted({c for v in agg.values() for c in v})
+        lines += [f"## counters ({os.path.basename(path)})", "", "| kernel | dispatches | " + " | ".join(counters) + " |",
+                  "|---|---:|" + "---:|" * len(counters)]
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].values()))[:20]:
+            n = max(1, len(calls[k]))
+            lines.append(f"| `{k}` | {n} | " + " | ".join(f"{v.get(c, 0) / n:.4g}" for c in counters) + " |")
+        lines += ["", "(counter values are per-dispatch means)", "", "| kernel | VGPR | AGPR | SGPR | LDS bytes | workgroup | grid |",
+                  "|---|---:|---:|---:|---:|---:|---:|"]
+        for k, r in regs.items():
+            lines.append(f"| `{k}` | " + " | ".join(r) + " |")
+        lines.append("")
+    with open(out, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print(f"wrote {out} ({len(lines)} lines)")
+
+
+if __name__ == "__main__":
+    main()

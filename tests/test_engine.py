@@ -252,7 +252,7 @@ def test_introspection(engine):
     i0 = E.introspect()
     time.sleep(0.5)
     i1 = E.introspect()
-    assert 1000 < i1["memory_kb"] < 500_000
+    assert 1000 < i1["memory_kb"] < 8_000_000  # RSS of this process: pytest (+ torch when other tests imported it)
     assert i1["sample_cycles"] > i0["sample_cycles"]
     assert 0 <= i1["cpu_percent"] < 50 and i1["avg_cycle_ms"] < 5
 

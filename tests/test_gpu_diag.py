@@ -1,0 +1,223 @@
+"""HIP diagnostics on a real MI355X, each kernel against a plain PyTorch fp32
+reference of the same operation.  (The reference repository has no active
+diagnostics and no GPU tests; its CI only builds: .travis.yml:1-14.)"""
+import math
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def diag():
+    from k8s_gpu_monitor_amd.ops import diag as d
+    assert d.device_count() >= 1
+    return d
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_native_library_is_the_one_running(diag):
+    info = diag.device_info(0)
+    assert info["gcn_arch"].startswith("gfx950") and info["compute_units"] == 256
+    assert info["total_mem"] > 250 << 30
+    maps = open("/proc/self/maps").read()
+    assert "libgpumon_diag.so" in maps
+
+
+# ------------------------------------------------------------------ HBM stream --
+@pytest.mark.parametrize("nt", [False, True, "auto"])
+@pytest.mark.parametrize("n", [4, 1024, 4 * 1000 * 1000 + 4, 16 << 20])
+def test_stream_kernels_match_torch(diag, dev, n, nt):
+    g = torch.Generator(device=dev).manual_seed(n)
+    a0 = torch.randn(n, device=dev, generator=g)
+    b0 = torch.randn(n, device=dev, generator=g)
+    c0 = torch.randn(n, device=dev, generator=g)
+    s = 1.75
+
+    def run(kernel):
+        a, b, c = a0.clone(), b0.clone(), c0.clone()
+        diag.hbm_stream_launch(kernel, a.data_ptr(), b.data_ptr(), c.data_ptr(), s, n, nt, _stream())
+        torch.cuda.synchronize()
+        return a, b, c
+
+    a, b, c = run("copy")
+    assert torch.equal(c, a0) and torch.equal(a, a0) and torch.equal(b, b0)
+    a, b, c = run("scale")
+    assert torch.equal(b, s * c0) and torch.equal(c, c0)
+    a, b, c = run("add")
+    assert torch.equal(c, a0 + b0)
+    a, b, c = run("triad")
+    assert torch.allclose(a, b0 + s * c0, rtol=1e-6, atol=1e-6)  # fma vs mul+add rounding
+    a, b, c = run("write")
+    assert torch.equal(a, torch.full_like(a, s)) and torch.equal(b, b0)
+    # read: partial sums per workgroup land in the sink; their total is sum(a)
+    sink = torch.zeros(32768, device=dev)
+    diag.hbm_stream_launch("read", a0.data_ptr(), 0, sink.data_ptr(), 0.0, n, nt, _stream())
+    torch.cuda.synchronize()
+    want = a0.double().sum().item()
+    assert sink.double().sum().item() == pytest.approx(want, abs=1e-3 * math.sqrt(n) + 1e-3)
+
+
+def test_stream_rejects_bad_arguments(diag, dev):
+    a = torch.zeros(1024, device=dev)
+    with pytest.raises(diag.DiagError):
+        diag.hbm_stream_launch("copy", a.data_ptr(), 0, 0, 0.0, 1024)        # no destination
+    with pytest.raises(diag.DiagError):
+        diag.hbm_stream_launch("copy", a.data_ptr(), 0, a.data_ptr(), 0.0, 1023)  # not a multiple of 4
+    with pytest.raises(diag.DiagError):
+        diag.hbm_stream_launch("copy", a.data_ptr() + 4, 0, a.data_ptr(), 0.0, 512)  # misaligned
+
+
+def test_stream_bandwidth_is_hbm_class(diag):
+    """Loose floors (about half of what the kernels measure) that still rule out a broken launch plan."""
+    r = diag.hbm_stream("read", 2 << 30, iters=5)
+    c = diag.hbm_stream("copy", 2 << 30, iters=5)
+    t = diag.hbm_stream("triad", 2 << 30, iters=5)
+    assert r["verified"] and c["verified"] and t["verified"]
+    assert r["tbps_best"] > 3.5 and c["tbps_best"] > 2.8 and t["tbps_best"] > 2.8, (r, c, t)
+
+
+# --------------------------------------------------------------------- memtest --
+def test_memtest_patterns_fill_and_verify(diag, dev):
+    n_words = 1 << 20
+    buf = torch.zeros(n_words, dtype=torch.int64, device=dev)
+    for name in diag.PATTERNS:
+        diag.memtest_fill(buf.data_ptr(), n_words, name, seed=3, stream=_stream())
+        errs, log = diag.memtest_verify(buf.data_ptr(), n_words, name, seed=3, stream=_stream())
+        assert errs == 0 and log == [], name
+    # known contents of the simple patterns
+    diag.memtest_fill(buf.data_ptr(), n_words, "address", stream=_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(buf, 8 * torch.arange(n_words, dtype=torch.int64, device=dev))  # own byte offset
+    diag.memtest_fill(buf.data_ptr(), n_words, "address", base_word=1 << 33, stream=_stream())
+    torch.cuda.synchronize()
+    assert buf[5].item() == ((1 << 33) + 5) * 8  # chunks continue the address sequence
+    diag.memtest_fill(buf.data_ptr(), n_words, "checkerboard", stream=_stream())
+    torch.cuda.synchronize()
+    assert (buf[0::2] == -0x5555555555555556).all() and (buf[1::2] == 0x5555555555555555).all()  # 0xAAAA.. / 0x5555..
+    diag.memtest_fill(buf.data_ptr(), n_words, "inv_checkerboard", stream=_stream())
+    torch.cuda.synchronize()
+    assert (buf[1::2] == -0x5555555555555556).all() and (buf[0::2] == 0x5555555555555555).all()
+    diag.memtest_fill(buf.data_ptr(), n_words, "random", seed=1, stream=_stream())
+    torch.cuda.synchronize()
+    r1 = buf.clone()
+    diag.memtest_fill(buf.data_ptr(), n_words, "random", seed=2, stream=_stream())
+    torch.cuda.synchronize()
+    assert (r1 != buf).float().mean() > 0.99 and r1.unique().numel() > 0.99 * n_words  # seed matters, no repeats
+    bits = sum(((r1 >> i) & 1).float().mean().item() for i in range(64)) / 64
+    assert 0.49 < bits < 0.51
+
+
+def test_memtest_finds_a_single_flipped_bit(diag, dev):
+    n_words = 1 << 22
+    buf = torch.zeros(n_words, dtype=torch.int64, device=dev)
+    diag.memtest_fill(buf.data_ptr(), n_words, "random", seed=11, stream=_stream())
+    torch.cuda.synchronize()
+    good = buf[123457].item()
+    buf[123457] ^= 1 << 40
+    errs, log = diag.memtest_verify(buf.data_ptr(), n_words, "random", seed=11, stream=_stream())
+    assert errs == 1 and len(log) == 1
+    assert log[0]["byte_offset"] == 123457 * 8
+    assert log[0]["expected"] == good & 0xFFFFFFFFFFFFFFFF and log[0]["actual"] == (good ^ (1 << 40)) & 0xFFFFFFFFFFFFFFFF
+    # wrong seed: everything differs, the log is capped
+    errs, log = diag.memtest_verify(buf.data_ptr(), n_words, "random", seed=12, stream=_stream())
+    assert errs > 0.99 * n_words and len(log) == diag.MEMTEST_LOG
+
+
+def test_memtest_driver_with_injection(diag):
+    seen = []
+    r = diag.memtest(bytes=1 << 30, chunk_bytes=256 << 20, inject_offset=(300 << 20) + 64, inject_xor=0x10,
+                     progress=lambda f, what: seen.append(f))
+    assert r["bytes_tested"] == 1 << 30 and r["chunks"] == 4 and r["patterns_run"] == 7
+    assert r["errors"] == 7  # once per pattern
+    assert all(e["byte_offset"] == (300 << 20) + 64 and e["chunk"] == 1 and e["expected"] ^ e["actual"] == 0x10
+               for e in r["log"])
+    assert seen and seen[-1] == pytest.approx(1.0) and seen == sorted(seen)
+    clean = diag.memtest(bytes=1 << 30, patterns=diag.PATTERNS["random"] | diag.PATTERNS["address"])
+    assert clean["errors"] == 0 and clean["patterns_run"] == 2 and clean["write_tbps"] > 1.5 and clean["verify_tbps"] > 1.5
+
+
+# ------------------------------------------------------------------- MFMA GEMM --
+def _gemm_inputs(dev, m, n, k, dtype, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    a = torch.randn(m, k, device=dev, generator=g)
+    b = torch.randn(n, k, device=dev, generator=g)
+    if dtype == "bf16":
+        return a.bfloat16(), b.bfloat16()
+    return a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8", "mxfp8"])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1024), (1024, 256, 4096), (2048, 2048, 2048)])
+def test_gemm_matches_fp32_reference(diag, dev, dtype, shape):
+    m, n, k = shape
+    a, b = _gemm_inputs(dev, m, n, k, dtype, seed=m + n + k)
+    c = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=dev)
+    diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, _stream())
+    torch.cuda.synchronize()
+    ref = a.float() @ b.float().t()
+    assert torch.isfinite(c.float()).all()
+    err = (c.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 6e-3, err  # bf16 output rounding: 2^-8 relative
+    # every tile position is its own product: permuting rows of A permutes rows of C
+    perm = torch.randperm(m, device=dev)
+    c2 = torch.empty_like(c)
+    ap = a.view(torch.uint8 if dtype != "bf16" else torch.bfloat16)[perm].contiguous()
+    diag.gemm_launch(dtype, ap.data_ptr(), b.data_ptr(), c2.data_ptr(), m, n, k, _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(c2, c[perm])
+
+
+def test_gemm_rejects_shapes_the_tiling_cannot_cover(diag, dev):
+    x = torch.zeros(512, 512, dtype=torch.bfloat16, device=dev)
+    for m, n, k in [(500, 512, 512), (512, 384 + 1, 512), (512, 512, 96), (0, 512, 512)]:
+        with pytest.raises(diag.DiagError):
+            diag.gemm_launch("bf16", x.data_ptr(), x.data_ptr(), x.data_ptr(), m, n, k, _stream())
+    with pytest.raises(diag.DiagError):
+        diag.gemm_launch("mxfp8", x.data_ptr(), x.data_ptr(), x.data_ptr(), 512, 512, 192, _stream())
+
+
+def test_gemm_stress_and_pipe_peak(diag):
+    g = diag.gemm_stress("bf16", 4096, 4096, 4096, seconds=0.5)
+    assert g["verified"] == 1 and g["sdc_mismatches"] == 0 and g["launches"] >= 2 and g["tflops"] > 300
+    g8 = diag.gemm_stress("mxfp8", 4096, 4096, 4096, seconds=0.5)
+    assert g8["verified"] == 1 and g8["sdc_mismatches"] == 0 and g8["tflops"] > 600
+    p = diag.mfma_peak("bf16", seconds=0.3)
+    assert p["tflops"] > 1500 and 1000 < p["clock_mhz_est"] < 2600, p  # 2.5 PF dense peak at 2.4 GHz
+    p8 = diag.mfma_peak("mxfp8", seconds=0.3)
+    assert p8["tflops"] > 1.6 * p["tflops"]
+
+
+# ---------------------------------------------------------------- interconnect --
+def test_rccl_sweep_single_gpu(diag):
+    pts = diag.rccl_sweep(devices=[0], max_bytes=64 << 20, factor=64)
+    assert {p["op"] for p in pts} == set(diag.COLLECTIVES)
+    assert all(p["verified"] == 1 and p["ndev"] == 1 and p["time_us"] > 0 for p in pts)
+    assert diag.busbw_factor("all_reduce", 8) == pytest.approx(1.75)
+    assert diag.p2p_matrix(devices=[0]) == [[0.0]]
+    with pytest.raises(diag.DiagError):
+        diag.rccl_sweep(devices=[0, 0])
+
+
+def test_torch_distributed_sweep_on_rccl(dev):
+    import os
+    import torch.distributed as dist
+    from k8s_gpu_monitor_amd.parallel import collectives as C
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        pts = C.sweep(sizes=[4096, 16 << 20], device=dev)
+        assert {p.op for p in pts} == set(C.OPS) and all(p.verified for p in pts)
+    finally:
+        dist.destroy_process_group()

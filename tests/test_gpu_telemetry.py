@@ -1,0 +1,159 @@
+"""The amdsmi backend on a real MI355X: discovery, a 1 s-class field watch and the
+exporter, checked against independent oracles (the HIP runtime's view of the same
+device, and the GPU's reaction to a load we generate ourselves).
+
+The reference's only oracle is the human comparing sample output with nvidia-smi
+(bindings/go/samples/nvml/README.md); here the comparison is automated."""
+import os
+import statistics
+import time
+import urllib.request
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from k8s_gpu_monitor_amd import abi as A  # noqa: E402
+from k8s_gpu_monitor_amd import engine as E  # noqa: E402
+from k8s_gpu_monitor_amd.utils import promparse  # noqa: E402
+
+F = A.FI
+
+
+@pytest.fixture(scope="module")
+def hw():
+    assert torch.cuda.is_available()
+    E.init(backend="amdsmi")
+    yield
+    E.shutdown()
+
+
+def _bdf_of_hip_device0():
+    from k8s_gpu_monitor_amd.ops import diag
+    return diag.device_info(0)["pci_bdf"].lower()
+
+
+def _engine_index_of_hip0():
+    bdf = _bdf_of_hip_device0()
+    for i in range(E.device_count()):
+        if E.device_attributes(i)["pci_bdf"].lower() == bdf:
+            return i
+    raise AssertionError(f"HIP device 0 ({bdf}) not among the engine's GPUs")
+
+
+def test_discovery_matches_hip(hw):
+    assert E.device_count() >= 1
+    gpu = _engine_index_of_hip0()
+    a = E.device_attributes(gpu)
+    assert a["supported"] == 1 and "MI355" in a["name"] and a["gfx_target"].startswith("gfx950")
+    assert a["uuid"] and a["pci_bdf"].count(":") == 2
+    free, total = torch.cuda.mem_get_info(0)
+    assert a["vram_total_mib"] == pytest.approx(total / 2**20, rel=0.02)
+    assert a["num_cu"] == 256 and a["num_xcd"] == 8
+    assert a["gfx_clock_max_mhz"] >= 2000
+    assert a["device_path"].startswith("/dev/dri/renderD")
+    assert gpu in E.supported_devices()
+
+
+def test_status_is_plausible_and_blank_is_not_a_number(hw):
+    gpu = _engine_index_of_hip0()
+    s = E.device_status(gpu)
+    assert 10 <= s["temperature_c"] <= 110
+    assert 20 <= s["power_w"] <= 1500
+    assert 90 <= s["gfx_clock_mhz"] <= 2600
+    assert s["enc_util"] is None and s["dec_util"] is None  # MI355X has no video encoder; never a fake 0
+    assert s["ecc_ue"] in (0, None) or s["ecc_ue"] >= 0
+
+
+def test_load_is_visible_in_utilisation_power_and_vram(hw):
+    from k8s_gpu_monitor_amd.ops import diag
+    gpu = _engine_index_of_hip0()
+    g = E.group_create("load", [gpu])
+    fg = E.field_group_create("load", [F["GFX_UTIL"], F["POWER_USAGE"], F["VRAM_USED"], F["GFX_CLOCK"], F["TOTAL_ENERGY"]])
+    E.watch_fields(g, fg, update_freq_us=100_000)
+    try:
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        E.update_all_fields(True)
+        idle = E.latest_values(gpu, [F["GFX_UTIL"], F["POWER_USAGE"], F["VRAM_USED"], F["TOTAL_ENERGY"]])
+        ballast = torch.empty(8 << 30, dtype=torch.uint8, device="cuda:0").fill_(1)
+        t0 = int(time.time() * 1e6)
+        r = diag.gemm_stress("bf16", 8192, 8192, 8192, seconds=3.0, verify=False)
+        assert r["tflops"] > 300
+        E.update_all_fields(True)
+        busy = E.latest_values(gpu, [F["VRAM_USED"], F["TOTAL_ENERGY"]])
+        util = [v for _, v in E.values_since(gpu, F["GFX_UTIL"], t0) if v is not None]
+        power = [v for _, v in E.values_since(gpu, F["POWER_USAGE"], t0) if v is not None]
+        assert len(util) >= 15  # 100 ms watch over >= 3 s
+        assert max(util) >= 90 and statistics.median(util) >= 50, util
+        assert max(power) > idle[F["POWER_USAGE"]] + 200, (idle, max(power))
+        if idle[F["VRAM_USED"]] is None:
+            # hosts that do not expose the kernel's VRAM counter: blank, never a made-up 0
+            assert busy[F["VRAM_USED"]] is None and not os.path.exists(
+                f"/sys/bus/pci/devices/{_bdf_of_hip_device0()}/mem_info_vram_used")
+        else:
+            assert busy[F["VRAM_USED"]] >= idle[F["VRAM_USED"]] + 8000  # MiB
+        joules = (busy[F["TOTAL_ENERGY"]] - idle[F["TOTAL_ENERGY"]]) / 1000.0  # field is in mJ
+        assert 0.5 * statistics.mean(power) * 3.0 < joules < 3.0 * max(power) * 5.0
+        del ballast
+    finally:
+        E.unwatch_fields(g, fg)
+        E.group_destroy(g)
+        E.field_group_destroy(fg)
+
+
+def test_exporter_scrape_latency_and_format(hw):
+    with E.Exporter(interval_ms=1000, listen="127.0.0.1:0", profiling=True, extras=True, self_metrics=True) as ex:
+        ex.start()
+        url = f"http://127.0.0.1:{ex.port}/metrics"
+        time.sleep(1.2)
+        lat = []
+        body = ""
+        for _ in range(50):
+            t = time.perf_counter()
+            body = urllib.request.urlopen(url, timeout=5).read().decode()
+            lat.append((time.perf_counter() - t) * 1e3)
+        fam = promparse.parse(body)
+        assert statistics.median(lat) < 50.0, lat  # the stack's headline target
+        n = E.device_count()
+        for name in ("dcgm_gpu_temp", "dcgm_power_usage", "dcgm_sm_clock", "dcgm_memory_clock", "dcgm_gpu_utilization"):
+            assert len(fam[name].samples) == n, name
+        # a family whose every sample is blank on this host is left out, never rendered as 0
+        vram_known = E.latest_values(0, [F["VRAM_USED"]])[F["VRAM_USED"]] is not None
+        assert ("dcgm_fb_used" in fam) == vram_known
+        labels, temp = fam["dcgm_gpu_temp"].samples[0]
+        assert labels["uuid"] and 10 <= temp <= 110
+        assert "dcgm_enc_utilization" not in fam or not fam["dcgm_enc_utilization"].samples  # blank: omitted
+        assert any(k.startswith("gpumon_xgmi") for k in fam)
+
+
+def test_sampling_overhead_is_small(hw):
+    """EVERY field of the registry on every GPU at 10 Hz — ten times the production rate — for 3 s."""
+    ids = E.field_list()
+    assert len(ids) > 60
+    g = E.group_create("ovh", list(range(E.device_count())))
+    fg = E.field_group_create("ovh", ids)
+    E.watch_fields(g, fg, update_freq_us=100_000)
+    try:
+        t0, c0 = time.time(), sum(os.times()[:2])
+        time.sleep(3.0)
+        cpu = (sum(os.times()[:2]) - c0) / (time.time() - t0)
+        assert cpu < 0.10, f"{cpu * 100:.1f} % of a core at 10 Hz"
+    finally:
+        E.unwatch_fields(g, fg)
+        E.group_destroy(g)
+        E.field_group_destroy(fg)
+
+
+def test_own_process_is_attributed(hw):
+    gpu = _engine_index_of_hip0()
+    keep = torch.ones(1 << 28, device="cuda:0")  # 1 GiB
+    torch.cuda.synchronize()
+    procs = E.device_processes(gpu)
+    if not procs:
+        pytest.skip("the driver exposes no per-process table to this user")
+    mine = [p for p in procs if p["pid"] == os.getpid()]
+    assert mine and mine[0]["vram_bytes"] >= 1 << 30
+    del keep
