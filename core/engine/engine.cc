@@ -790,7 +790,7 @@ gm_status_t LocalEngine::event_unsubscribe(uint32_t sub) {
 
 // ------------------------------------------------------------------ values --
 
-static void static_value(const GpuStatic& s, uint16_t id, gm_value_t* o) {
+void static_value(const GpuStatic& s, uint16_t id, gm_value_t* o) {
   auto str = [&](const std::string& x) {
     o->type = GM_FT_STRING;
     if (x.empty()) { o->status = GM_VS_NOT_SUPPORTED; return; }
@@ -928,16 +928,34 @@ gm_status_t LocalEngine::fake_ctl(const std::string& cmd) { return backend_->con
 
 // ------------------------------------------------------------------ status --
 
-static const uint16_t kStatusFields[] = {
+const uint16_t kStatusFields[] = {
     GM_FI_POWER_USAGE, GM_FI_GPU_TEMP, GM_FI_GFX_UTIL, GM_FI_MEM_UTIL, GM_FI_ENC_UTIL, GM_FI_DEC_UTIL,
     GM_FI_GFX_CLOCK, GM_FI_MEM_CLOCK, GM_FI_DEV_VIS_VRAM_USED, GM_FI_PCIE_RX_KB, GM_FI_PCIE_TX_KB,
     GM_FI_PCIE_REPLAY_COUNTER, GM_FI_VRAM_USED, GM_FI_VRAM_FREE, GM_FI_ECC_CE_AGGREGATE, GM_FI_ECC_UE_AGGREGATE,
     GM_FI_PERF_LEVEL, GM_FI_FAN_SPEED, GM_FI_THROTTLE_STATUS, GM_FI_MEM_TEMP, GM_FI_TOTAL_ENERGY};
+const int kNumStatusFields = (int)(sizeof kStatusFields / sizeof kStatusFields[0]);
+
+void fill_status(uint32_t gpu, const gm_value_t* vals, gm_device_status_t* out) {
+  uint32_t ver = out->version;
+  memset(out, 0, sizeof *out);
+  out->version = ver;
+  out->gpu = gpu;
+  int64_t* ints[] = {nullptr, &out->temperature_c, &out->gfx_util, &out->mem_util, &out->enc_util, &out->dec_util,
+                     &out->gfx_clock_mhz, &out->mem_clock_mhz, &out->vis_vram_used_mib, &out->pcie_rx_kb,
+                     &out->pcie_tx_kb, &out->pcie_replays, &out->vram_used_mib, &out->vram_free_mib, &out->ecc_ce,
+                     &out->ecc_ue, &out->perf_level, &out->fan_speed, &out->throttle_status, &out->mem_temp_c,
+                     &out->energy_mj};
+  for (int i = 0; i < kNumStatusFields; i++) {
+    if (vals[i].status != GM_VS_OK) continue;
+    out->valid |= 1ull << i;
+    if (i == GM_DS_POWER) out->power_w = vals[i].v.dbl; else *ints[i] = vals[i].v.i64;
+  }
+}
 
 gm_status_t LocalEngine::device_status(uint32_t gpu, gm_device_status_t* out) {
   if (gpu >= gpus_.size()) return GM_ST_BADPARAM;
   if (!gpus_[gpu]->st.supported) return GM_ST_GPU_NOT_SUPPORTED;
-  const int n = (int)(sizeof kStatusFields / sizeof kStatusFields[0]);
+  const int n = kNumStatusFields;
   bool fresh = false;
   {
     std::lock_guard<std::mutex> l(state_mu_);
@@ -952,23 +970,10 @@ gm_status_t LocalEngine::device_status(uint32_t gpu, gm_device_status_t* out) {
     gm_status_t st = update_all(true);
     if (st != GM_ST_OK) return st;
   }
-  gm_value_t vals[sizeof kStatusFields / sizeof kStatusFields[0]];
-  gm_status_t st = latest_values(gpu, kStatusFields, n, vals);
+  std::vector<gm_value_t> vals(n);
+  gm_status_t st = latest_values(gpu, kStatusFields, n, vals.data());
   if (st != GM_ST_OK) return st;
-  uint32_t ver = out->version;
-  memset(out, 0, sizeof *out);
-  out->version = ver;
-  out->gpu = gpu;
-  int64_t* ints[] = {nullptr, &out->temperature_c, &out->gfx_util, &out->mem_util, &out->enc_util, &out->dec_util,
-                     &out->gfx_clock_mhz, &out->mem_clock_mhz, &out->vis_vram_used_mib, &out->pcie_rx_kb,
-                     &out->pcie_tx_kb, &out->pcie_replays, &out->vram_used_mib, &out->vram_free_mib, &out->ecc_ce,
-                     &out->ecc_ue, &out->perf_level, &out->fan_speed, &out->throttle_status, &out->mem_temp_c,
-                     &out->energy_mj};
-  for (int i = 0; i < n; i++) {
-    if (vals[i].status != GM_VS_OK) continue;
-    out->valid |= 1ull << i;
-    if (i == GM_DS_POWER) out->power_w = vals[i].v.dbl; else *ints[i] = vals[i].v.i64;
-  }
+  fill_status(gpu, vals.data(), out);
   return GM_ST_OK;
 }
 

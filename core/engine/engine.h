@@ -300,5 +300,11 @@ const char* policy_condition_name(uint32_t condition);
 const char* event_code_name(uint32_t code);
 const char* status_string(gm_status_t st);
 void fill_attributes(const GpuStatic& s, gm_device_attributes_t* out);
+// Value of a static (read-once) field out of the attribute cache.
+void static_value(const GpuStatic& s, uint16_t id, gm_value_t* out);
+// The fields behind gm_device_status_t, in GM_DS_* bit order, and the struct fill from their values.
+extern const uint16_t kStatusFields[];
+extern const int kNumStatusFields;
+void fill_status(uint32_t gpu, const gm_value_t* vals, gm_device_status_t* out);
 
 }  // namespace gpumon

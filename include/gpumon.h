@@ -740,6 +740,29 @@ GM_API gm_status_t gm_render_view(int view, uint32_t id, int json, char* out, si
 GM_API gm_status_t gm_format_violation(const gm_violation_t* v, char* out, size_t* len);
 GM_API const char* gm_event_code_name(uint32_t code);
 
+/* ------------------------------------------------------ direct device layer -- */
+/* The "smi" path: every call goes straight to the device library, with no host
+ * engine, no sampler thread and no cache — the role the NVML package plays in the
+ * reference next to its DCGM package (bindings/go/nvml/nvml.go:274-604).  It has
+ * its own refcounted lifetime, independent of gm_init. */
+GM_API gm_status_t gm_smi_init(const char* backend /* NULL = "amdsmi" */, const char* backend_spec);
+GM_API gm_status_t gm_smi_shutdown(void);
+GM_API gm_status_t gm_smi_device_count(uint32_t* count);
+GM_API gm_status_t gm_smi_driver_version(char* buf, size_t cap);
+GM_API gm_status_t gm_smi_device_attributes(uint32_t gpu, gm_device_attributes_t* out);
+/* One synchronous read of everything gm_device_status_t holds. */
+GM_API gm_status_t gm_smi_device_status(uint32_t gpu, gm_device_status_t* out);
+/* One synchronous read of arbitrary fields (one device-library round per source). */
+GM_API gm_status_t gm_smi_read_fields(uint32_t gpu, const uint16_t* field_ids, int n, gm_value_t* out);
+GM_API gm_status_t gm_smi_device_processes(uint32_t gpu, gm_process_t* out, int* n);
+GM_API gm_status_t gm_smi_peer_link(uint32_t gpu, uint32_t peer, gm_peer_link_t* out);
+GM_API gm_status_t gm_smi_device_mode(uint32_t gpu, gm_device_mode_t* out);
+/* Blocks up to timeout_ms for the next driver event (reset, RAS, thermal...);
+ * GM_ST_TIMEOUT when none arrived, GM_ST_NOT_SUPPORTED when the platform has no event channel. */
+GM_API gm_status_t gm_smi_event_wait(int32_t timeout_ms, gm_event_t* out);
+/* Scripts the fake backend owned by the direct layer (tests); NOT_SUPPORTED on real hardware. */
+GM_API gm_status_t gm_smi_fake_ctl(const char* command);
+
 /* ---------------------------------------------------------------- logging -- */
 GM_API void gm_set_log_level(int level); /* 0 error, 1 warn, 2 info, 3 debug */
 

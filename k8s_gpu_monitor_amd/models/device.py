@@ -51,11 +51,14 @@ class Device:
     memory_partition: str = ""
     topology: List[P2PLink] = field(default_factory=list)
 
+    api: object = field(default=E, repr=False, compare=False)  # engine (cached) or smi (direct) module
+
     def status(self) -> "DeviceStatus":
-        return device_status(self.index)
+        return device_status(self.index, api=self.api)
 
     def processes(self) -> List["ProcessInfo"]:
-        return [ProcessInfo(p["pid"], p["name"], p["vram_bytes"] >> 20, "C") for p in E.device_processes(self.index)]
+        return [ProcessInfo(p["pid"], p["name"], p["vram_bytes"] >> 20, "C")
+                for p in self.api.device_processes(self.index)]
 
 
 @dataclass
@@ -104,8 +107,9 @@ class DeviceStatus:
         return [n for b, n in self.THROTTLE_NAMES.items() if self.throttle & b]
 
 
-def new_device(index: int, lite: bool = False) -> Device:
-    a = E.device_attributes(index)
+def new_device(index: int, lite: bool = False, api=E) -> Device:
+    """api: :mod:`engine` (values from the sampler cache) or :mod:`smi` (direct device reads)."""
+    a = api.device_attributes(index)
     if not a["supported"] or not a["uuid"]:
         raise E.GpumonError(A.GM_ST_GPU_NOT_SUPPORTED, f"device {index}")
     nanv = lambda x: None if x != x else int(round(x))  # noqa: E731
@@ -118,18 +122,18 @@ def new_device(index: int, lite: bool = False) -> Device:
                     None if lite else opt(a["pcie_bandwidth_mbs"])),
         clocks=ClockInfo(None if lite else opt(a["gfx_clock_max_mhz"]), None if lite else opt(a["mem_clock_max_mhz"])),
         gfx_target=a["gfx_target"] or None, num_xcd=a["num_xcd"], num_cu=a["num_cu"],
-        compute_partition=a["compute_partition"], memory_partition=a["memory_partition"])
+        compute_partition=a["compute_partition"], memory_partition=a["memory_partition"], api=api)
     if not lite:
         from .._lib import lib
-        for p in E.device_topology(index)["peers"]:
+        for p in api.device_topology(index)["peers"]:
             dev.topology.append(P2PLink(p["pci_bdf"], p["link_name"], lib().gm_link_type_description(p["link"]).decode()))
     return dev
 
 
-def device_status(index: int) -> DeviceStatus:
-    s = E.device_status(index)
+def device_status(index: int, api=E) -> DeviceStatus:
+    s = api.device_status(index)
     kb_to_mb = lambda x: None if x is None else x // 1000  # noqa: E731
-    procs = [ProcessInfo(p["pid"], p["name"], p["vram_bytes"] >> 20, "C") for p in E.device_processes(index)]
+    procs = [ProcessInfo(p["pid"], p["name"], p["vram_bytes"] >> 20, "C") for p in api.device_processes(index)]
     return DeviceStatus(
         power=None if s["power_w"] is None else int(s["power_w"]), temperature=s["temperature_c"],
         utilization=UtilizationInfo(s["gfx_util"], s["mem_util"], s["enc_util"], s["dec_util"]),
