@@ -481,7 +481,8 @@ class AmdSmiBackend : public Backend {
       memset(&p, 0, sizeof p);
       if (api_.amdsmi_get_power_cap_info(d.h, 0, &p) == AMDSMI_STATUS_SUCCESS) {
         s.power_cap_w = (double)p.power_cap / 1e6;  // µW on bare metal
-        s.power_cap_default_w = (double)p.default_power_cap / 1e6;
+        // 0 is the library's "not reported" (seen on MI355X with ROCm 7.2), not a 0 W default.
+        if (p.default_power_cap > 0) s.power_cap_default_w = (double)p.default_power_cap / 1e6;
         s.power_cap_max_w = (double)p.max_power_cap / 1e6;
       }
     }

@@ -322,7 +322,7 @@ class FakeBackend : public Backend {
   gm_status_t poll_events(int timeout_ms, std::vector<DeviceEvent>* out) override {
     if (!events_supported_) return GM_ST_NOT_SUPPORTED;
     std::unique_lock<std::mutex> l(mu_);
-    ev_cv_.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return !events_.empty() || gpus_.empty(); });
+    cv_wait_for(ev_cv_, l, std::chrono::milliseconds(timeout_ms), [&] { return !events_.empty() || gpus_.empty(); });
     while (!events_.empty()) {
       out->push_back(events_.front());
       events_.pop_front();

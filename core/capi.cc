@@ -538,7 +538,7 @@ gm_status_t gm_policy_wait(gm_policy_reg_t reg, int32_t timeout_ms, gm_violation
     q = it->second;
   }
   std::unique_lock<std::mutex> l(q->mu);
-  if (!q->cv.wait_for(l, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms), [&] { return !q->q.empty(); }))
+  if (!cv_wait_for(q->cv, l, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms), [&] { return !q->q.empty(); }))
     return GM_ST_TIMEOUT;
   *out = q->q.front();
   q->q.pop_front();
@@ -628,7 +628,7 @@ gm_status_t gm_event_wait(gm_event_set_t es, int32_t timeout_ms, gm_event_t* out
     s = it->second;
   }
   std::unique_lock<std::mutex> l(s->mu);
-  if (!s->cv.wait_for(l, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms), [&] { return !s->q.empty(); }))
+  if (!cv_wait_for(s->cv, l, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms), [&] { return !s->q.empty(); }))
     return GM_ST_TIMEOUT;
   *out = s->q.front();
   s->q.pop_front();

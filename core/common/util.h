@@ -1,6 +1,8 @@
 // Small shared helpers: clocks, logging, string and file utilities.
 #pragma once
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -35,6 +37,20 @@ inline void copy_str(char* dst, size_t cap, const std::string& src) {
   size_t n = src.size() < cap - 1 ? src.size() : cap - 1;
   memcpy(dst, src.data(), n);
   dst[n] = 0;
+}
+
+// Timed condition-variable wait on the monotonic clock.  ThreadSanitizer builds
+// route it through the system clock instead: libstdc++ implements steady-clock
+// waits with pthread_cond_clockwait, which GCC 11's libtsan does not intercept —
+// it then believes the mutex stays locked across the wait and floods the report
+// with "double lock" and bogus races.
+template <class CV, class Lock, class Rep, class Period, class Pred>
+inline bool cv_wait_for(CV& cv, Lock& lock, const std::chrono::duration<Rep, Period>& d, Pred pred) {
+#if defined(__SANITIZE_THREAD__)
+  return cv.wait_until(lock, std::chrono::system_clock::now() + d, pred);
+#else
+  return cv.wait_for(lock, d, pred);
+#endif
 }
 
 std::vector<std::string> split(const std::string& s, char sep);

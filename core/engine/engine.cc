@@ -577,12 +577,12 @@ gm_status_t LocalEngine::update_all(bool wait) {
   wake_cv_.notify_all();
   if (!wait) return GM_ST_OK;
   // The sampler records the highest force request it has fully served.
-  bool ok = cycle_cv_.wait_for(l, std::chrono::seconds(30), [&] { return cycles_ >= target || !running_; });
+  bool ok = cv_wait_for(cycle_cv_, l, std::chrono::seconds(30), [&] { return cycles_ >= target || !running_; });
   return ok ? GM_ST_OK : GM_ST_TIMEOUT;
 }
 
-void LocalEngine::sample_gpu(uint32_t gpu, uint32_t sources, const std::vector<uint8_t>& due, int64_t now_mono,
-                             int64_t now_wall) {
+void LocalEngine::sample_gpu(uint32_t gpu, uint32_t sources, const std::vector<uint8_t>& due,
+                             const std::vector<SlotWatch>& watch, int64_t now_mono, int64_t now_wall) {
   GpuState& g = *gpus_[gpu];
   static thread_local Sample sample;
   sample.clear();
@@ -618,7 +618,7 @@ void LocalEngine::sample_gpu(uint32_t gpu, uint32_t sources, const std::vector<u
   }
   for (int slot = 0; slot < nslots; slot++) {
     if (!sample.touched[slot] || !due[slot]) continue;
-    const SlotWatch& sw = g.watch[slot];
+    const SlotWatch& sw = watch[slot];
     auto& h = g.history[slot];
     h.push_back(HistoryPoint{now_wall, sample.v[slot]});
     if (sw.keep_samples > 0)
@@ -633,6 +633,10 @@ void LocalEngine::sampler_loop() {
   const int nslots = field_count();
   std::vector<std::vector<uint8_t>> due(gpus_.size(), std::vector<uint8_t>(nslots, 0));
   std::vector<uint32_t> sources(gpus_.size(), 0);
+  // The sampler's own copy of the retention settings: control-plane calls replace
+  // GpuState::watch under state_mu_ while a sample cycle runs outside that lock.
+  std::vector<std::vector<SlotWatch>> watch_snap(gpus_.size());
+  uint64_t snap_gen = ~0ull;
   while (running_) {
     bool forced;
     uint64_t serving;
@@ -648,8 +652,11 @@ void LocalEngine::sampler_loop() {
     bool any = false, pid_due = false;
     {
       std::lock_guard<std::mutex> l(state_mu_);
+      const bool resnap = watch_gen_.load() != snap_gen;
+      snap_gen = watch_gen_.load();
       for (size_t gi = 0; gi < gpus_.size(); gi++) {
         GpuState& g = *gpus_[gi];
+        if (resnap) watch_snap[gi] = g.watch;
         sources[gi] = 0;
         std::fill(due[gi].begin(), due[gi].end(), 0);
         for (int s = 0; s < nslots; s++) {
@@ -678,7 +685,7 @@ void LocalEngine::sampler_loop() {
     if (any || pid_due) {
       int64_t t0 = monotonic_us();
       for (size_t gi = 0; gi < gpus_.size(); gi++)
-        if (sources[gi]) sample_gpu((uint32_t)gi, sources[gi], due[gi], now_mono, now_wall);
+        if (sources[gi]) sample_gpu((uint32_t)gi, sources[gi], due[gi], watch_snap[gi], now_mono, now_wall);
       if (pid_due) accounting_tick(now_mono, now_wall);
       evaluate_policies(now_wall);
       int64_t dt = monotonic_us() - t0;
@@ -695,7 +702,7 @@ void LocalEngine::sampler_loop() {
       uint64_t gen = watch_gen_.load();
       int64_t wait_us = next_deadline - monotonic_us();
       if (wait_us > 0)
-        wake_cv_.wait_for(l, std::chrono::microseconds(wait_us),
+        cv_wait_for(wake_cv_, l, std::chrono::microseconds(wait_us),
                           [&] { return force_ || !running_ || watch_gen_.load() != gen; });
     }
   }

@@ -240,7 +240,10 @@ class LocalEngine : public Engine {
 
   void sampler_loop();
   void event_loop();
-  void sample_gpu(uint32_t gpu, uint32_t sources, const std::vector<uint8_t>& due, int64_t now_mono, int64_t now_wall);
+  // due[slot] != 0: append to the slot's history; retention comes from `watch`, the
+  // sampler's own copy of the watch table taken under state_mu_.
+  void sample_gpu(uint32_t gpu, uint32_t sources, const std::vector<uint8_t>& due, const std::vector<SlotWatch>& watch,
+                  int64_t now_mono, int64_t now_wall);
   void publish(GpuState& g, int slot, const SlotValue& v, int64_t ts);
   bool read_cell(GpuState& g, int slot, SlotValue* v, int64_t* ts);
   void rebuild_watch_table();  // state_mu_ held

@@ -369,7 +369,7 @@ void Exporter::loop() {
     {
       std::unique_lock<std::mutex> l(wake_mu_);
       int64_t now = monotonic_us();
-      if (next > now) wake_cv_.wait_for(l, std::chrono::microseconds(next - now), [&] { return !running_.load(); });
+      if (next > now) cv_wait_for(wake_cv_, l, std::chrono::microseconds(next - now), [&] { return !running_.load(); });
     }
     if (!running_) break;
     if ((st = publish()) != GM_ST_OK) GM_LOGW("exporter publish failed: %s", status_string(st));

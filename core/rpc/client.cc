@@ -337,7 +337,7 @@ class RemoteEngine : public Engine {
       }
     }
     std::unique_lock<std::mutex> l(mu_);
-    bool ok = cv_.wait_for(l, std::chrono::seconds(60), [&] { return pending_[id].done || dead_; });
+    bool ok = cv_wait_for(cv_, l, std::chrono::seconds(60), [&] { return pending_[id].done || dead_; });
     Pending p = std::move(pending_[id]);
     pending_.erase(id);
     if (!ok) return GM_ST_TIMEOUT;

@@ -40,7 +40,12 @@ void RpcServer::stop() {
     cs.swap(clients_);
   }
   for (auto& c : cs) {
-    shutdown(c->fd, SHUT_RDWR);
+    {
+      // serve() closes the descriptor under write_mu when its peer leaves first;
+      // never shut down a number that may already belong to someone else.
+      std::lock_guard<std::mutex> l(c->write_mu);
+      if (c->fd >= 0) shutdown(c->fd, SHUT_RDWR);
+    }
     if (c->th.joinable()) c->th.join();
   }
 }

@@ -1,0 +1,331 @@
+// C++ tests of the core library, meant to run under ThreadSanitizer and
+// AddressSanitizer as well as plainly (make test / make tsan / make asan):
+// the sampler <-> reader hand-off, concurrent control-plane calls, the RPC
+// server with several clients, and the text parsers on hostile input.
+// Plain asserts; no test framework.
+#include <unistd.h>
+
+#include <atomic>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <thread>
+
+#include "core/common/json.h"
+#include "core/common/util.h"
+#include "core/exporter/exporter.h"
+#include "core/fields.h"
+#include "core/rpc/server.h"
+#include "gpumon.h"
+
+using namespace gpumon;
+
+#define CHECK(x)                                                        \
+  do {                                                                  \
+    if (!(x)) {                                                         \
+      fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #x); \
+      abort();                                                          \
+    }                                                                   \
+  } while (0)
+#define OK(expr) CHECK((expr) == GM_ST_OK)
+
+static void init_fake(const char* spec) {
+  gm_init_params_t p;
+  memset(&p, 0, sizeof p);
+  p.version = GM_INIT_PARAMS_VERSION;
+  p.mode = GM_MODE_EMBEDDED;
+  p.backend = "fake";
+  p.backend_spec = spec;
+  OK(gm_init(&p));
+}
+
+// -- field registry invariants -------------------------------------------------
+static void test_registry() {
+  std::vector<uint16_t> ids(1024);
+  int n = (int)ids.size();
+  OK(gm_field_list(ids.data(), &n));
+  CHECK(n > 60 && n == field_count());
+  for (int i = 0; i < n; i++) {
+    gm_field_meta_t m;
+    OK(gm_field_meta(ids[i], &m));
+    CHECK(m.field_id == ids[i] && m.tag && m.tag[0]);
+    uint16_t back = 0;
+    OK(gm_field_by_tag(m.tag, &back));
+    CHECK(back == ids[i]);
+    CHECK(field_slot(ids[i]) == i);
+    for (int j = 0; j < i; j++) CHECK(ids[j] != ids[i]);  // ids are unique
+  }
+  CHECK(gm_field_meta(9999, nullptr) != GM_ST_OK);
+  printf("registry: %d fields ok\n", n);
+}
+
+// -- sampler vs readers vs control plane, all at once ---------------------------
+static void test_concurrent_engine() {
+  init_fake("gpus=8,seed=3");
+  uint32_t ngpu = 0;
+  OK(gm_device_count(&ngpu));
+  CHECK(ngpu == 8);
+  std::vector<uint16_t> all(1024);
+  int nf = (int)all.size();
+  OK(gm_field_list(all.data(), &nf));
+  gm_group_t g;
+  gm_field_group_t fg;
+  OK(gm_group_create("stress", &g));
+  for (uint32_t i = 0; i < ngpu; i++) OK(gm_group_add_device(g, i));
+  OK(gm_field_group_create(all.data(), nf, "stress", &fg));
+  OK(gm_watch_fields(g, fg, 1000, 1.0, 0));  // 1 kHz: the sampler is always mid-publish
+  OK(gm_health_set(g, GM_HEALTH_WATCH_ALL));
+  gm_policy_t pol;
+  memset(&pol, 0, sizeof pol);
+  pol.version = GM_POLICY_VERSION;
+  pol.conditions = GM_POLICY_COND_ALL;
+  pol.max_bad_pages = 10;
+  pol.thermal_c = 60;
+  pol.power_w = 900;
+  pol.hysteresis_pct = 3;
+  OK(gm_policy_set(g, &pol));
+
+  std::atomic<bool> stop{false};
+  std::atomic<uint64_t> reads{0}, violations{0}, torn{0};
+  std::vector<std::thread> th;
+  for (int r = 0; r < 4; r++)
+    th.emplace_back([&, r] {
+      uint16_t ids[] = {GM_FI_GPU_TEMP, GM_FI_POWER_USAGE, GM_FI_GFX_CLOCK, GM_FI_VRAM_USED, GM_FI_VRAM_FREE, GM_FI_VRAM_TOTAL};
+      gm_value_t v[6];
+      while (!stop) {
+        uint32_t gpu = (uint32_t)(reads.load() + r) % 8;
+        OK(gm_latest_values(gpu, ids, 6, v));
+        // One call = one published state: used + free must add up to total whenever all three are there.
+        if (v[3].status == GM_VS_OK && v[4].status == GM_VS_OK && v[5].status == GM_VS_OK &&
+            v[3].v.i64 + v[4].v.i64 != v[5].v.i64)
+          torn++;
+        gm_device_status_t ds;
+        memset(&ds, 0, sizeof ds);
+        ds.version = GM_DEVICE_STATUS_VERSION;
+        OK(gm_device_status(gpu, &ds));
+        std::vector<gm_value_t> hist(256);
+        int hn = (int)hist.size();
+        gm_status_t st = gm_values_since(gpu, GM_FI_GPU_TEMP, 0, hist.data(), &hn);
+        CHECK(st == GM_ST_OK || st == GM_ST_INSUFFICIENT_SIZE);
+        for (int i = 1; i < hn && i < 256; i++) CHECK(hist[i].ts_us >= hist[i - 1].ts_us);
+        reads++;
+      }
+    });
+  th.emplace_back([&] {  // exporter rendering from the same cache
+    gm_exporter_config_t c;
+    memset(&c, 0, sizeof c);
+    c.version = GM_EXPORTER_CONFIG_VERSION;
+    c.interval_ms = 100;
+    c.profiling = c.amd_extras = c.self_metrics = 1;
+    gm_exporter_t ex;
+    OK(gm_exporter_create(&c, &ex));
+    std::vector<char> buf(1 << 20);
+    while (!stop) {
+      size_t len = buf.size();
+      OK(gm_exporter_render(ex, buf.data(), &len));
+      CHECK(len > 1000 && strstr(buf.data(), "# TYPE dcgm_gpu_temp gauge"));  // single GPUs may be blanked by the injector
+    }
+    OK(gm_exporter_destroy(ex));
+  });
+  th.emplace_back([&] {  // fault injector
+    std::mt19937 rng(7);
+    const char* cmds[] = {"set gpu=%u field=150 value=95", "clear gpu=%u field=150", "ecc gpu=%u block=0 ue=1",
+                          "link_down gpu=%u link=2", "link_up gpu=%u link=2", "event gpu=%u code=5 msg=x",
+                          "unsupported gpu=%u field=155", "pcie_replay gpu=%u count=3", "fail gpu=%u", "fail gpu=%u sources=0"};
+    while (!stop) {
+      char b[128];
+      snprintf(b, sizeof b, cmds[rng() % 10], (unsigned)(rng() % 8));
+      gm_fake_ctl(b);
+      usleep(500);
+    }
+  });
+  th.emplace_back([&] {  // registrations come and go while violations are being delivered
+    while (!stop) {
+      gm_policy_reg_t reg;
+      OK(gm_policy_register(g, GM_POLICY_COND_ALL, [](const gm_violation_t*, void* u) -> int { (*(std::atomic<uint64_t>*)u)++; return 0; },
+                            &violations, &reg));
+      usleep(3000);
+      gm_violation_t v;
+      gm_policy_wait(reg, 1, &v);
+      OK(gm_policy_unregister(reg));
+    }
+  });
+  th.emplace_back([&] {  // group / watch churn next to the running sampler
+    int k = 0;
+    while (!stop) {
+      gm_group_t g2;
+      gm_field_group_t f2;
+      char name[32];
+      snprintf(name, sizeof name, "churn-%d", k++);
+      OK(gm_group_create(name, &g2));
+      OK(gm_group_add_device(g2, k % 8));
+      uint16_t ids[] = {GM_FI_GPU_TEMP, GM_FI_ECC_UE_VOLATILE};
+      OK(gm_field_group_create(ids, 2, name, &f2));
+      OK(gm_watch_fields(g2, f2, 2000, 0.5, 16));
+      gm_health_response_t hr[GM_MAX_GPUS];
+      int hn = GM_MAX_GPUS;
+      hr[0].version = GM_HEALTH_RESPONSE_VERSION;
+      OK(gm_health_set(g2, GM_HEALTH_WATCH_ALL));
+      OK(gm_health_check(g2, hr, &hn));
+      OK(gm_unwatch_fields(g2, f2));
+      OK(gm_field_group_destroy(f2));
+      OK(gm_group_destroy(g2));
+    }
+  });
+  sleep(2);
+  stop = true;
+  for (auto& t : th) t.join();
+  gm_introspect_t in;
+  memset(&in, 0, sizeof in);
+  in.version = GM_INTROSPECT_VERSION;
+  OK(gm_introspect(&in));
+  printf("concurrent engine: %llu reads, %llu violations, %llu sample cycles, torn=%llu\n", (unsigned long long)reads.load(),
+         (unsigned long long)violations.load(), (unsigned long long)in.sample_cycles, (unsigned long long)torn.load());
+  CHECK(reads > 100 && in.sample_cycles > 100 && torn == 0);
+  OK(gm_shutdown());
+}
+
+// -- RPC: several clients against one server -----------------------------------
+static void test_rpc() {
+  init_fake("gpus=4,seed=1");
+  char path[] = "/tmp/gpumon-test-XXXXXX";
+  int fd = mkstemp(path);
+  close(fd);
+  unlink(path);
+  OK(gm_server_start(path, 1));
+  std::atomic<uint64_t> got{0};
+  std::vector<std::thread> th;
+  for (int c = 0; c < 4; c++)
+    th.emplace_back([&, c] {
+      gm_status_t st;
+      std::string err;
+      auto eng = make_remote_engine(path, true, 3000, &st, &err);
+      CHECK(eng && st == GM_ST_OK);
+      uint32_t n = 0;
+      OK(eng->device_count(&n));
+      CHECK(n == 4);
+      gm_group_t g;
+      gm_field_group_t fg;
+      OK(eng->group_create("c" + std::to_string(c), &g));
+      OK(eng->group_add(g, c));
+      OK(eng->field_group_create({GM_FI_GPU_TEMP, GM_FI_POWER_USAGE}, "c" + std::to_string(c), &fg));
+      OK(eng->watch_fields(g, fg, 2000, 1.0, 0));
+      gm_policy_t pol;
+      memset(&pol, 0, sizeof pol);
+      pol.version = GM_POLICY_VERSION;
+      pol.conditions = GM_POLICY_COND_THERMAL;
+      pol.thermal_c = 80;
+      pol.hysteresis_pct = 3;
+      OK(eng->policy_set(g, pol));
+      gm_policy_reg_t reg;
+      OK(eng->policy_register(g, GM_POLICY_COND_THERMAL, [&](const gm_violation_t& v) { if (v.gpu == (uint32_t)c) got++; }, &reg));
+      OK(eng->fake_ctl("set gpu=" + std::to_string(c) + " field=150 value=97"));
+      for (int i = 0; i < 200; i++) {
+        uint16_t ids[] = {GM_FI_GPU_TEMP, GM_FI_POWER_USAGE};
+        gm_value_t v[2];
+        OK(eng->update_all(i % 20 == 0));
+        OK(eng->latest_values(c, ids, 2, v));
+        gm_device_status_t ds;
+        memset(&ds, 0, sizeof ds);
+        ds.version = GM_DEVICE_STATUS_VERSION;
+        OK(eng->device_status(c, &ds));
+      }
+      if (c % 2) OK(eng->policy_unregister(reg));  // the others leave the clean-up to the disconnect
+    });
+  for (auto& t : th) t.join();
+  CHECK(got >= 4);
+  gm_group_t g;
+  OK(gm_group_create("c0", &g));  // names of disconnected clients are free again
+  OK(gm_server_stop());
+  OK(gm_shutdown());
+  printf("rpc: %llu violations over 4 connections ok\n", (unsigned long long)got.load());
+}
+
+// -- parsers on hostile input ----------------------------------------------------
+static void test_parsers() {
+  Json j;
+  CHECK(json_parse("{\"a\":[1,2,{\"b\":\"x\\n\\u0041\"}],\"c\":-1.5e2,\"d\":null,\"e\":true}", &j));
+  CHECK(j.get("a") && j.get("a")->arr.size() == 3 && j.get("a")->arr[2].get("b")->str == "x\nA");
+  CHECK(j.get("c")->num == -150.0);
+  const char* bad[] = {"", "{", "{\"a\":}", "[1,,2]", "{\"a\":1}x", "\"unterminated", "{\"a\":tru}", "[1e999999]x", "nul"};
+  for (const char* b : bad) CHECK(!json_parse(b, &j));
+  std::mt19937 rng(11);
+  const char alphabet[] = "{}[]\",:\\ntruefalsn0123456789.-eE \n\tabc\x01\xff";
+  for (int i = 0; i < 20000; i++) {
+    std::string s;
+    int len = rng() % 64;
+    for (int k = 0; k < len; k++) s += alphabet[rng() % (sizeof alphabet - 1)];
+    json_parse(s, &j);  // must not crash or hang
+    PodMap m;
+    parse_device_plugin_checkpoint(s, "amd.com/gpu", &m);
+  }
+  std::string deep(100000, '[');
+  CHECK(!json_parse(deep, &j));  // nesting is bounded, no stack overflow
+
+  PodMap m = parse_pod_map_tsv("GPU-1\tpod\tns\tc\n#comment\nbroken line\namdgpu3\tp2\t\tc2\n");
+  CHECK(m.size() == 2 && m["GPU-1"].pod == "pod" && m["amdgpu3"].ns.empty());
+  const char la[] = "{}\"\\,= \nabcgpuuid0123#";
+  for (int i = 0; i < 20000; i++) {
+    std::string s;
+    int len = rng() % 96;
+    for (int k = 0; k < len; k++) s += la[rng() % (sizeof la - 1)];
+    std::string out = relabel_text(s, m, "amdgpu");
+    CHECK(out.size() >= s.size());
+  }
+  std::string text = "m{gpu=\"3\",uuid=\"GPU-x\"} 1\nm{gpu=\"0\",uuid=\"GPU-1\"} 2\n";
+  std::string out = relabel_text(text, m, "amdgpu");
+  CHECK(out.find("m{gpu=\"3\",uuid=\"GPU-x\",pod_name=\"p2\",pod_namespace=\"\",container_name=\"c2\"} 1\n") == 0);
+  CHECK(out.find("uuid=\"GPU-1\",pod_name=\"pod\"") != std::string::npos);
+  CHECK(relabel_text(out, m, "amdgpu") == out);
+  printf("parsers ok\n");
+}
+
+// -- refcount + direct layer ------------------------------------------------------
+static void test_lifecycles() {
+  CHECK(gm_shutdown() == GM_ST_UNINITIALIZED);
+  init_fake("gpus=2");
+  init_fake("gpus=5");
+  CHECK(gm_init_refcount() == 2);
+  OK(gm_shutdown());
+  uint32_t n = 0;
+  OK(gm_device_count(&n));
+  CHECK(n == 2);
+  OK(gm_shutdown());
+  CHECK(gm_device_count(&n) == GM_ST_UNINITIALIZED);
+  for (int i = 0; i < 20; i++) {  // start/stop leaves no thread or descriptor behind
+    init_fake("gpus=8");
+    OK(gm_update_all_fields(1));
+    OK(gm_shutdown());
+  }
+  OK(gm_smi_init("fake", "gpus=3"));
+  std::vector<std::thread> th;
+  for (int t = 0; t < 4; t++)
+    th.emplace_back([t] {
+      for (int i = 0; i < 500; i++) {
+        gm_device_status_t ds;
+        memset(&ds, 0, sizeof ds);
+        ds.version = GM_DEVICE_STATUS_VERSION;
+        OK(gm_smi_device_status(t % 3, &ds));
+        CHECK(ds.valid & (1ull << GM_DS_TEMP));
+      }
+    });
+  for (auto& t : th) t.join();
+  OK(gm_smi_shutdown());
+  CHECK(gm_smi_shutdown() == GM_ST_UNINITIALIZED);
+  printf("lifecycles ok\n");
+}
+
+int main() {
+  gm_set_log_level(0);
+  test_lifecycles();
+  init_fake("gpus=1");
+  test_registry();
+  OK(gm_shutdown());
+  test_parsers();
+  test_concurrent_engine();
+  test_rpc();
+  printf("ALL OK\n");
+  return 0;
+}
