@@ -1,0 +1,337 @@
+package smi
+
+import (
+	"errors"
+	"fmt"
+	"math"
+	"strings"
+	"time"
+)
+
+// Public data model.  Same shape as the reference's nvml package
+// (bindings/go/nvml/nvml.go:23-266): pointer members are optional and nil when the
+// device does not report the value — never a sentinel number.
+
+// ThrottleReason is a bit of DeviceStatus.Throttle.
+type ThrottleReason uint
+
+const (
+	ThrottlePowerCap ThrottleReason = 1 << iota
+	ThrottleThermal
+	ThrottleHBMThermal
+	ThrottleVRThermal
+	ThrottleProcHot
+	ThrottleLowUtilization
+	ThrottleHostLimit
+)
+
+func (t ThrottleReason) String() string {
+	if t == 0 {
+		return "No clocks throttling"
+	}
+	names := []string{"Power cap", "Thermal", "HBM thermal", "VR thermal", "PROCHOT", "Low utilization", "Host limit"}
+	var on []string
+	for i, n := range names {
+		if t&(1<<uint(i)) != 0 {
+			on = append(on, n)
+		}
+	}
+	return strings.Join(on, ", ")
+}
+
+// P2PLinkType classifies the path between two GPUs.
+type P2PLinkType uint
+
+func (l P2PLinkType) String() string { return linkDescription(uint(l)) }
+
+// P2PLink is one peer of a GPU: the PEER's bus id and how it is reached ("XGMI1", "PIX", "SYS"...).
+type P2PLink struct {
+	BusID string
+	Link  P2PLinkType
+	Name  string
+}
+
+type ClockInfo struct {
+	Cores  *uint // MHz
+	Memory *uint // MHz
+}
+
+type PCIInfo struct {
+	BusID       string
+	VisibleVRAM *uint64 // MiB; the BAR1 analog (all of HBM on MI355X: large BAR)
+	Bandwidth   *uint   // MB/s, from the maximum link generation and width
+}
+
+// Device is the static identity of one GPU.
+type Device struct {
+	Index            uint
+	UUID             string
+	Path             string // /dev/dri/renderD<N>
+	Model            *string
+	Power            *uint   // W, enforced power cap
+	Memory           *uint64 // MiB of HBM
+	CPUAffinity      *uint   // NUMA node
+	PCI              PCIInfo
+	Clocks           ClockInfo // maximum clocks
+	Topology         []P2PLink
+	GfxTarget        string // e.g. gfx950; the compute-capability analog
+	NumXCD, NumCU    uint
+	ComputePartition string // SPX, DPX, QPX, CPX
+	MemoryPartition  string // NPS1, NPS2, ...
+	Serial, VBIOS    string
+}
+
+type UtilizationInfo struct {
+	GPU     *uint // %
+	Memory  *uint // % (HBM controller activity)
+	Encoder *uint // nil on MI355X: there is no video encoder
+	Decoder *uint
+}
+
+type ECCErrorsInfo struct {
+	Correctable   *uint64
+	Uncorrectable *uint64
+}
+
+type MemoryInfo struct {
+	Used      *uint64 // MiB
+	Free      *uint64 // MiB
+	ECCErrors ECCErrorsInfo
+}
+
+type PCIThroughputInfo struct {
+	RX *uint // MB/s
+	TX *uint
+}
+
+type ProcessInfo struct {
+	PID         uint
+	Name        string
+	MemoryUsed  uint64 // MiB
+	CUOccupancy *uint
+}
+
+// DeviceStatus is one telemetry read.
+type DeviceStatus struct {
+	Power       *uint // W
+	Temperature *uint // °C, hotspot
+	HBMTemp     *uint // °C
+	Utilization UtilizationInfo
+	Memory      MemoryInfo
+	Clocks      ClockInfo
+	PCI         PCIThroughputInfo
+	Processes   []ProcessInfo
+	Throttle    *ThrottleReason
+	Performance *uint
+	EnergyJ     *float64 // energy counter since driver load
+}
+
+// DeviceMode reports partitioning; the reference reports display / persistence /
+// accounting modes here (nvml.go:582-604), none of which exist on a compute-only part.
+type DeviceMode struct {
+	ComputePartition string
+	MemoryPartition  string
+}
+
+// Event is a driver notification (GPU reset, RAS error, thermal throttle ...): the
+// counterpart of the reference's XID events (bindings.go:68-146).
+type Event struct {
+	GPU     uint
+	UUID    string
+	Code    uint
+	Name    string
+	Message string
+	Time    time.Time
+}
+
+var ErrUnsupportedGPU = errors.New("unsupported GPU device")
+
+// Init loads the device library and enumerates GPUs.  Reference-counted.
+func Init() error { return initLib("", "") }
+
+// InitWithBackend selects a backend explicitly ("amdsmi" or "fake") — tests use the fake.
+func InitWithBackend(backend, spec string) error { return initLib(backend, spec) }
+
+func Shutdown() error { return shutdownLib() }
+
+func GetDeviceCount() (uint, error) { return deviceCount() }
+
+func GetDriverVersion() (string, error) { return driverVersion() }
+
+func optUint(v int64, ok bool) *uint {
+	if !ok || v < 0 {
+		return nil
+	}
+	u := uint(v)
+	return &u
+}
+
+func optU64(v int64, ok bool) *uint64 {
+	if !ok || v < 0 {
+		return nil
+	}
+	u := uint64(v)
+	return &u
+}
+
+func newDevice(idx uint, lite bool) (*Device, error) {
+	a, err := deviceAttributes(idx)
+	if err != nil {
+		return nil, err
+	}
+	if !a.supported || a.uuid == "" {
+		return nil, ErrUnsupportedGPU
+	}
+	d := &Device{Index: idx, UUID: a.uuid, Path: a.path, GfxTarget: a.gfxTarget, NumXCD: a.numXCD, NumCU: a.numCU,
+		ComputePartition: a.computePart, MemoryPartition: a.memPart, Serial: a.serial, VBIOS: a.vbios}
+	d.PCI.BusID = a.busID
+	d.CPUAffinity = optUint(int64(a.numaNode), a.numaNode >= 0)
+	if a.name != "" {
+		name := a.name
+		d.Model = &name
+	}
+	if lite {
+		return d, nil
+	}
+	if !math.IsNaN(a.powerCapW) {
+		d.Power = optUint(int64(math.Round(a.powerCapW)), true)
+	}
+	d.Memory = optU64(a.vramTotalMiB, true)
+	d.PCI.VisibleVRAM = optU64(a.visVramTotalMiB, true)
+	d.PCI.Bandwidth = optUint(a.pcieBandwidthMBs, true)
+	d.Clocks.Cores = optUint(a.gfxClockMaxMHz, true)
+	d.Clocks.Memory = optUint(a.memClockMaxMHz, true)
+	n, err := deviceCount()
+	if err != nil {
+		return nil, err
+	}
+	for peer := uint(0); peer < n; peer++ {
+		if peer == idx {
+			continue
+		}
+		l, err := peerLink(idx, peer)
+		if isStatus(err, StatusNotSupported) {
+			d.Topology = nil
+			break
+		}
+		if err != nil {
+			return nil, err
+		}
+		d.Topology = append(d.Topology, P2PLink{BusID: l.busID, Link: P2PLinkType(l.link), Name: linkName(l.link, l.hops)})
+	}
+	return d, nil
+}
+
+// NewDevice reads the full static description of GPU idx, including its topology.
+func NewDevice(idx uint) (*Device, error) { return newDevice(idx, false) }
+
+// NewDeviceLite reads only identity (UUID, path, bus id, model, NUMA node): what a
+// device plugin needs at start-up.
+func NewDeviceLite(idx uint) (*Device, error) { return newDevice(idx, true) }
+
+// Status performs one synchronous telemetry read.
+func (d *Device) Status() (*DeviceStatus, error) {
+	s, err := deviceStatus(d.Index)
+	if err != nil {
+		return nil, err
+	}
+	ok := func(bit uint) bool { return s.valid&(1<<bit) != 0 }
+	st := &DeviceStatus{}
+	if ok(0) {
+		st.Power = optUint(int64(s.powerW), true) // truncated, like the reference's mW -> W
+	}
+	st.Temperature = optUint(s.temp, ok(1))
+	st.Utilization = UtilizationInfo{GPU: optUint(s.gfxUtil, ok(2)), Memory: optUint(s.memUtil, ok(3)),
+		Encoder: optUint(s.encUtil, ok(4)), Decoder: optUint(s.decUtil, ok(5))}
+	st.Clocks = ClockInfo{Cores: optUint(s.gfxClock, ok(6)), Memory: optUint(s.memClock, ok(7))}
+	st.PCI = PCIThroughputInfo{RX: optUint(s.pcieRxKB/1000, ok(9)), TX: optUint(s.pcieTxKB/1000, ok(10))}
+	st.Memory = MemoryInfo{Used: optU64(s.vramUsed, ok(12)), Free: optU64(s.vramFree, ok(13)),
+		ECCErrors: ECCErrorsInfo{Correctable: optU64(s.eccCE, ok(14)), Uncorrectable: optU64(s.eccUE, ok(15))}}
+	st.Performance = optUint(s.perfLevel, ok(16))
+	if ok(18) {
+		t := ThrottleReason(s.throttle)
+		st.Throttle = &t
+	}
+	st.HBMTemp = optUint(s.memTemp, ok(19))
+	if ok(20) {
+		j := float64(s.energyMilliJ) / 1000.0
+		st.EnergyJ = &j
+	}
+	procs, err := d.GetAllRunningProcesses()
+	if err != nil && !isStatus(err, StatusNotSupported) && !isStatus(err, StatusNoPermission) {
+		return nil, err
+	}
+	st.Processes = procs
+	return st, nil
+}
+
+// GetAllRunningProcesses lists the processes that hold the GPU.
+func (d *Device) GetAllRunningProcesses() ([]ProcessInfo, error) {
+	raw, err := deviceProcesses(d.Index)
+	if err != nil {
+		return nil, err
+	}
+	out := make([]ProcessInfo, 0, len(raw))
+	for _, p := range raw {
+		pi := ProcessInfo{PID: p.pid, Name: p.name, MemoryUsed: p.vramBytes >> 20}
+		if p.cuOccupancy != 0xffffffff {
+			cu := p.cuOccupancy
+			pi.CUOccupancy = &cu
+		}
+		out = append(out, pi)
+	}
+	return out, nil
+}
+
+// GetP2PLink classifies the path between two devices.
+func GetP2PLink(dev1, dev2 *Device) (P2PLinkType, string, error) {
+	l, err := peerLink(dev1.Index, dev2.Index)
+	if err != nil {
+		return 0, "", err
+	}
+	return P2PLinkType(l.link), linkName(l.link, l.hops), nil
+}
+
+// GetXGMILink reports whether two devices are directly connected over xGMI and
+// with how many links; the counterpart of GetNVLink (nvml.go:539-568).
+func GetXGMILink(dev1, dev2 *Device) (connected bool, links uint, err error) {
+	l, err := peerLink(dev1.Index, dev2.Index)
+	if err != nil {
+		return false, 0, err
+	}
+	name := linkName(l.link, l.hops)
+	return strings.HasPrefix(name, "XGMI"), l.numLinks, nil
+}
+
+func (d *Device) GetDeviceMode() (*DeviceMode, error) {
+	c, m, err := deviceMode(d.Index)
+	if err != nil {
+		return nil, err
+	}
+	return &DeviceMode{ComputePartition: c, MemoryPartition: m}, nil
+}
+
+// ReadFields reads arbitrary registry fields (ids from the C header, GM_FI_*) in
+// one round; entries are int64, float64, string or nil.
+func (d *Device) ReadFields(ids []uint16) ([]interface{}, error) { return readFields(d.Index, ids) }
+
+// WaitForEvent blocks up to timeout for the next driver event; (nil, nil) on timeout.
+func WaitForEvent(timeout time.Duration) (*Event, error) {
+	e, err := eventWait(int(timeout / time.Millisecond))
+	if isStatus(err, StatusTimeout) {
+		return nil, nil
+	}
+	if err != nil {
+		return nil, err
+	}
+	return &Event{GPU: e.gpu, UUID: e.uuid, Code: e.code, Name: eventName(e.code), Message: e.msg,
+		Time: time.UnixMicro(e.tsMicros)}, nil
+}
+
+func (d *Device) String() string {
+	model := "unknown"
+	if d.Model != nil {
+		model = *d.Model
+	}
+	return fmt.Sprintf("GPU %d: %s (%s) %s", d.Index, model, d.UUID, d.PCI.BusID)
+}
