@@ -89,12 +89,7 @@ static_assert(kMaxGrid <= GMD_STREAM_SINK_FLOATS, "a caller-provided READ sink m
 
 // Grid and span (in 16-byte elements, a multiple of one unrolled workgroup pass).
 inline void plan(uint64_t n4, unsigned* grid, uint64_t* span) {
-  const uint64_t pass = (uint64_t)kBlock * kUnroll;
-  uint64_t passes = (n4 + pass - 1) / pass;
-  uint64_t g = std::max<uint64_t>(1, std::min<uint64_t>(passes, kMaxGrid));
-  uint64_t per = (passes + g - 1) / g;
-  *span = per * pass;
-  *grid = (unsigned)((n4 + *span - 1) / *span);
+  gmd::span_plan(n4, (uint64_t)kBlock * kUnroll, kMaxGrid, grid, span);
 }
 
 __global__ void init_kernel(f32x4* a, f32x4* b, f32x4* c, uint64_t n4) {

@@ -5,10 +5,12 @@
 // test covers twice the memory a copy-compare test could.  Patterns follow the
 // classic memory-test repertoire (walking ones / zeros, address-in-address,
 // checkerboard and its inverse, a counter-based pseudo-random fill, modulo-20).
-// Both passes move 16 bytes per lane per access (two 64-bit words) from a
-// grid-stride loop sized for 256 CUs; mismatches are counted with one atomic
-// per mismatching lane (rare) and the first few are logged with offset,
-// expected and actual value so a failing HBM stack / channel can be located.
+// Both passes move 16 bytes per lane per access (two 64-bit words); every
+// workgroup walks its own contiguous span (128 workgroups per CU) and the
+// pattern is a template parameter, so the inner loop is loads / stores plus a few
+// integer ops.  Mismatches are counted with one atomic per mismatching lane
+// (rare) and the first few are logged with offset, expected and actual value so
+// a failing HBM stack / channel can be located.
 //
 // The region is allocated in chunks (default 2 GiB) so a fragmented heap still
 // yields high coverage; allocation stops at the first failure and the achieved
@@ -44,13 +46,28 @@ __host__ __device__ __forceinline__ uint64_t expected_word(uint32_t pattern, uin
   return 0;
 }
 
-__global__ __launch_bounds__(kBlock) void fill_kernel(u64x2* __restrict__ buf, uint64_t n2, uint64_t base_word,
-                                                      uint32_t pattern, uint64_t seed) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+constexpr unsigned kMaxGrid = gmd::kCUs * 128;
+
+// PAT is a compile-time constant so the pattern switch folds away; every workgroup
+// walks its own contiguous span (see gmd::span_plan).
+template <uint32_t PAT>
+__global__ __launch_bounds__(kBlock) void fill_kernel(u64x2* __restrict__ buf, uint64_t n2, uint64_t span,
+                                                      uint64_t base_word, uint64_t seed) {
+  uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x;
+  const uint64_t end = min((uint64_t)(blockIdx.x + 1) * span, n2);
+  for (; i + (kUnroll - 1) * kBlock < end; i += kUnroll * kBlock) {
+    u64x2 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+      const uint64_t w = base_word + 2 * (i + u * kBlock);
+      v[u] = u64x2{expected_word(PAT, w, seed), expected_word(PAT, w + 1, seed)};
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) buf[i + u * kBlock] = v[u];  // plain stores: a pure-store stream is faster without nt
+  }
+  for (; i < end; i += kBlock) {
     const uint64_t w = base_word + 2 * i;
-    u64x2 v = {expected_word(pattern, w, seed), expected_word(pattern, w + 1, seed)};
-    buf[i] = v;  // plain stores: the pure-store stream measures faster without the nt hint
+    buf[i] = u64x2{expected_word(PAT, w, seed), expected_word(PAT, w + 1, seed)};
   }
 }
 
@@ -73,29 +90,70 @@ __device__ __forceinline__ void report(VerifyOut* out, uint64_t word, uint64_t e
   }
 }
 
-__global__ __launch_bounds__(kBlock) void verify_kernel(const u64x2* __restrict__ buf, uint64_t n2, uint64_t base_word,
-                                                        uint32_t pattern, uint64_t seed, VerifyOut* out) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  for (; i + (kUnroll - 1) * stride < n2; i += kUnroll * stride) {
+template <uint32_t PAT>
+__global__ __launch_bounds__(kBlock) void verify_kernel(const u64x2* __restrict__ buf, uint64_t n2, uint64_t span,
+                                                        uint64_t base_word, uint64_t seed, VerifyOut* out) {
+  uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x;
+  const uint64_t end = min((uint64_t)(blockIdx.x + 1) * span, n2);
+  for (; i + (kUnroll - 1) * kBlock < end; i += kUnroll * kBlock) {
     u64x2 v[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; u++) v[u] = __builtin_nontemporal_load(buf + i + u * stride);
+    for (int u = 0; u < kUnroll; u++) v[u] = __builtin_nontemporal_load(buf + i + u * kBlock);
+    // One cheap combined test per pass; the per-word reporting runs only when it trips.
+    uint64_t diff = 0;
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
-      const uint64_t w = base_word + 2 * (i + u * stride);
-      const uint64_t e0 = expected_word(pattern, w, seed), e1 = expected_word(pattern, w + 1, seed);
-      if (v[u].x != e0) report(out, w, e0, v[u].x, pattern);
-      if (v[u].y != e1) report(out, w + 1, e1, v[u].y, pattern);
+      const uint64_t w = base_word + 2 * (i + u * kBlock);
+      diff |= (v[u].x ^ expected_word(PAT, w, seed)) | (v[u].y ^ expected_word(PAT, w + 1, seed));
+    }
+    if (diff) {
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {
+        const uint64_t w = base_word + 2 * (i + u * kBlock);
+        const uint64_t e0 = expected_word(PAT, w, seed), e1 = expected_word(PAT, w + 1, seed);
+        if (v[u].x != e0) report(out, w, e0, v[u].x, PAT);
+        if (v[u].y != e1) report(out, w + 1, e1, v[u].y, PAT);
+      }
     }
   }
-  for (; i < n2; i += stride) {
+  for (; i < end; i += kBlock) {
     u64x2 v = __builtin_nontemporal_load(buf + i);
     const uint64_t w = base_word + 2 * i;
-    const uint64_t e0 = expected_word(pattern, w, seed), e1 = expected_word(pattern, w + 1, seed);
-    if (v.x != e0) report(out, w, e0, v.x, pattern);
-    if (v.y != e1) report(out, w + 1, e1, v.y, pattern);
+    const uint64_t e0 = expected_word(PAT, w, seed), e1 = expected_word(PAT, w + 1, seed);
+    if (v.x != e0) report(out, w, e0, v.x, PAT);
+    if (v.y != e1) report(out, w + 1, e1, v.y, PAT);
   }
+}
+
+// Host-side dispatch from the run-time pattern bit to the compile-time instance.
+#define GMD_FOR_PATTERN(pattern, CALL)                                   \
+  switch (pattern) {                                                     \
+    case GMD_PAT_WALKING_ONES: CALL(GMD_PAT_WALKING_ONES); break;        \
+    case GMD_PAT_WALKING_ZEROS: CALL(GMD_PAT_WALKING_ZEROS); break;      \
+    case GMD_PAT_ADDRESS: CALL(GMD_PAT_ADDRESS); break;                  \
+    case GMD_PAT_CHECKERBOARD: CALL(GMD_PAT_CHECKERBOARD); break;        \
+    case GMD_PAT_INV_CHECKERBOARD: CALL(GMD_PAT_INV_CHECKERBOARD); break; \
+    case GMD_PAT_RANDOM: CALL(GMD_PAT_RANDOM); break;                    \
+    case GMD_PAT_MODULO_20: CALL(GMD_PAT_MODULO_20); break;              \
+  }
+
+void launch_fill(u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t pattern, uint64_t seed, hipStream_t st) {
+  unsigned grid;
+  uint64_t span;
+  gmd::span_plan(n2, (uint64_t)kBlock * kUnroll, kMaxGrid, &grid, &span);
+#define CALL(P) fill_kernel<P><<<grid, kBlock, 0, st>>>(buf, n2, span, base_word, seed)
+  GMD_FOR_PATTERN(pattern, CALL)
+#undef CALL
+}
+
+void launch_verify(const u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t pattern, uint64_t seed, VerifyOut* out,
+                   hipStream_t st) {
+  unsigned grid;
+  uint64_t span;
+  gmd::span_plan(n2, (uint64_t)kBlock * kUnroll, kMaxGrid, &grid, &span);
+#define CALL(P) verify_kernel<P><<<grid, kBlock, 0, st>>>(buf, n2, span, base_word, seed, out)
+  GMD_FOR_PATTERN(pattern, CALL)
+#undef CALL
 }
 
 __global__ void xor_word_kernel(unsigned long long* p, unsigned long long mask) { *p ^= mask; }
@@ -113,8 +171,7 @@ extern "C" {
 int gmd_memtest_fill(void* buf, uint64_t n_words, uint64_t base_word, uint32_t pattern, uint64_t seed, void* hip_stream) {
   if (!buf || !n_words || (n_words & 1) || ((uintptr_t)buf & 15) || !valid_pattern(pattern)) return GMD_ERR_BADPARAM;
   const uint64_t n2 = n_words / 2;
-  fill_kernel<<<gmd::stream_grid(n2, kBlock, kUnroll), kBlock, 0, (hipStream_t)hip_stream>>>((u64x2*)buf, n2, base_word,
-                                                                                          pattern, seed);
+  launch_fill((u64x2*)buf, n2, base_word, pattern, seed, (hipStream_t)hip_stream);
   GMD_HIP(hipGetLastError());
   return GMD_OK;
 }
@@ -129,8 +186,7 @@ int gmd_memtest_verify(const void* buf, uint64_t n_words, uint64_t base_word, ui
   hipError_t e = hipMemsetAsync(d, 0, sizeof(VerifyOut), st);
   const uint64_t n2 = n_words / 2;
   if (e == hipSuccess) {
-    verify_kernel<<<gmd::stream_grid(n2, kBlock, kUnroll), kBlock, 0, st>>>((const u64x2*)buf, n2, base_word, pattern,
-                                                                           seed, d);
+    launch_verify((const u64x2*)buf, n2, base_word, pattern, seed, d, st);
     e = hipGetLastError();
   }
   VerifyOut h;
@@ -221,7 +277,7 @@ int gmd_memtest(int device, const gmd_memtest_config_t* cfg_in, gmd_memtest_resu
       (void)hipEventRecord(e0, 0);
       for (auto& c : chunks) {
         const uint64_t n2 = c.bytes / 16;
-        fill_kernel<<<gmd::stream_grid(n2, kBlock, kUnroll), kBlock>>>((u64x2*)c.p, n2, c.base_word, pat, seed);
+        launch_fill((u64x2*)c.p, n2, c.base_word, pat, seed, 0);
       }
       (void)hipEventRecord(e1, 0);
       err = hipEventSynchronize(e1);
@@ -242,8 +298,7 @@ int gmd_memtest(int device, const gmd_memtest_config_t* cfg_in, gmd_memtest_resu
       (void)hipEventRecord(e0, 0);
       for (auto& c : chunks) {
         const uint64_t n2 = c.bytes / 16;
-        verify_kernel<<<gmd::stream_grid(n2, kBlock, kUnroll), kBlock>>>((const u64x2*)c.p, n2, c.base_word, pat, seed,
-                                                                       d_out);
+        launch_verify((const u64x2*)c.p, n2, c.base_word, pat, seed, d_out, 0);
       }
       (void)hipEventRecord(e1, 0);
       err = hipEventSynchronize(e1);

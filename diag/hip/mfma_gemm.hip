@@ -36,6 +36,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 
 #include "diag_common.h"
 
@@ -190,6 +192,250 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restric
     }
 }
 
+// ---- (2b) the same GEMM as a phase-interleaved pipeline -------------------------
+//
+// Same tile, same LDS image and swizzle, same MFMA operand order as gemm_kernel;
+// what changes is WHEN things happen.  The K loop runs in phases, four per K-tile,
+// one C quadrant (64x32 of the wave's 128x64) each:
+//
+//     [ds_read the fragments this or the next phase needs] [issue one half-tile of
+//     LDS-DMA] [s_waitcnt vmcnt(6)]  s_barrier  [16 MFMA (8 for MX-fp8)]  s_barrier
+//
+// * Operand tiles are staged in half-tiles of 128 rows x 128 B (16 KiB, two
+//   LDS-DMA instructions per wave), in the order the phases consume them:
+//   B-lo, A-lo, B-hi, A-hi of K-tile 0, B-lo of K-tile 1, ...  ("lo"/"hi" = the
+//   rows that the first / second quadrant pair of every wave reads).  Half-tile j
+//   is read in phase j-1 and lives in ring slot j % 8 (128 KiB in all).
+// * Phase q issues half-tile q+5 and then waits until at most three half-tiles
+//   (6 instructions) are outstanding, which retires half-tile q+2: everything a
+//   phase reads was waited for one phase earlier, by every wave, before a barrier
+//   the reader has passed.  The loop never drains to vmcnt(0).
+// * A slot is overwritten five phases... by half-tile j+8, issued in phase j+3,
+//   four phases after its last read.
+// * The two wave rows (wr = 0 / 1) share each SIMD and run one barrier apart, so
+//   while one row issues its MFMAs the other row issues its LDS reads and DMA:
+//   8 ds_read_b128 x 4 waves take the LDS pipe about as long as 16 MFMAs take the
+//   matrix pipe.  The B-lo fragments of the next K-tile are read into whichever
+//   B register set is idle, which makes the per-phase read counts 8 / 4 / 8 / 4.
+constexpr int kHalfBytes = 128 * BKB;  // one ring slot
+constexpr int kAhead = 5;              // half-tiles issued ahead of the running phase
+
+// Tile order: XCD-contiguous chunks (as above), walked in column-major groups of
+// four tile rows, so the ~32 tiles an XCD has in flight form a 4 x 8 block that
+// shares 4 A panels and 8 B panels in its L2 instead of 1 and 32.
+__device__ __forceinline__ void tile_of(int wgid, int tiles_m, int tiles_n, int* tm, int* tn) {
+  constexpr int G = 4;
+  const int per_group = G * tiles_n;
+  const int group = wgid / per_group;
+  const int first = group * G;
+  const int gm = min(tiles_m - first, G);
+  const int in = wgid - group * per_group;
+  *tm = first + in % gm;
+  *tn = in / gm;
+}
+
+// A fragment of the pipeline kernel is eight dwords: the two 16-byte LDS reads of one
+// 16-row block (bf16: K sub-steps 0 and 1; MX-fp8: the two halves of the K=128 operand).
+template <int MB0, int NB0, int DT>
+__device__ __forceinline__ void quadrant(f32x4 (&acc)[8][4], const i32x8 (&a)[4], const i32x8 (&b)[2]) {
+  if constexpr (DT == GMD_DT_BF16) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+          const i32x4 bh = ks ? __builtin_shufflevector(b[nb], b[nb], 4, 5, 6, 7) : __builtin_shufflevector(b[nb], b[nb], 0, 1, 2, 3);
+          const i32x4 ah = ks ? __builtin_shufflevector(a[mb], a[mb], 4, 5, 6, 7) : __builtin_shufflevector(a[mb], a[mb], 0, 1, 2, 3);
+          acc[MB0 + mb][NB0 + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, bh), __builtin_bit_cast(bf16x8, ah), acc[MB0 + mb][NB0 + nb], 0, 0, 0);
+        }
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+      for (int nb = 0; nb < 2; nb++)
+        acc[MB0 + mb][NB0 + nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[nb], a[mb], acc[MB0 + mb][NB0 + nb], 0, 0, 0,
+                                                                                 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#define GMD_PHASE_FENCE()                  \
+  __builtin_amdgcn_sched_barrier(0);       \
+  __builtin_amdgcn_s_barrier();            \
+  __builtin_amdgcn_sched_barrier(0)
+
+template <int DT>
+__global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restrict__ A, const char* __restrict__ B,
+                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8n = nwg & 7;
+  const int wgid = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (blockIdx.x >> 3);
+  int tm, tn;
+  tile_of(wgid, M / BM, N / BN, &tm, &tn);
+  const char* gA = A + (size_t)tm * BM * row_bytes;
+  const char* gB = B + (size_t)tn * BN * row_bytes;
+
+  // Staging: this wave fills pieces 2*wave and 2*wave+1 (8 rows x 128 B each) of every slot.
+  // Slot-local row l maps to tile row (l>>6)*128 + (l&63) [+64 for hi] in A and (l>>5)*64 + (l&31) [+32 for hi] in B.
+  const int r8 = lane >> 3;
+  const uint32_t src_chunk = (uint32_t)(((lane & 7) ^ chunk_swizzle<DT>(r8)) * 16);
+  uint32_t off_a[2], off_b[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int l = (2 * wave + i) * 8 + r8;
+    off_a[i] = (uint32_t)(((l >> 6) * 128 + (l & 63)) * row_bytes) + src_chunk;
+    off_b[i] = (uint32_t)(((l >> 5) * 64 + (l & 31)) * row_bytes) + src_chunk;
+  }
+  const size_t hi_a = 64 * row_bytes, hi_b = 32 * row_bytes;
+  char* const my_pieces = smem + wave * 2048;
+
+  // kind: 0 B-lo, 1 A-lo, 2 B-hi, 3 A-hi;  par: K-tile parity;  kt: K-tile index
+  auto issue = [&](auto KIND, auto PAR, int kt) {
+    constexpr int kind = decltype(KIND)::value, par = decltype(PAR)::value;
+    const char* base = ((kind & 1) ? gA + (kind == 3 ? hi_a : 0) : gB + (kind == 2 ? hi_b : 0)) + (size_t)kt * BKB;
+    // Keep the wave-uniform part of the address whole, in scalar registers: the DMA then takes "SGPR base +
+    // 32-bit lane offset" and the loop carries 4 offset VGPRs instead of eight 64-bit lane pointers.
+    asm volatile("" : "+s"(base));
+    char* dst = my_pieces + (par * 4 + kind) * kHalfBytes;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + ((kind & 1) ? off_a[i] : off_b[i])),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+
+  // Fragment read offsets inside a slot (local rows: A wr*64 + fr, B wc*32 + fr).
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    const int ch = DT == GMD_DT_BF16 ? ks * 4 + fq : 2 * fq + ks;
+    a_off[ks] = lds_off<DT>(wr * 64 + fr, ch);
+    b_off[ks] = lds_off<DT>(wc * 32 + fr, ch);
+  }
+  auto read_a = [&](i32x8 (&a)[4], int slot) {
+#pragma unroll
+    for (int mb = 0; mb < 4; mb++) {
+      const i32x4 lo = *(const i32x4*)(smem + slot * kHalfBytes + a_off[0] + mb * 2048);
+      const i32x4 hi = *(const i32x4*)(smem + slot * kHalfBytes + a_off[1] + mb * 2048);
+      a[mb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto read_b = [&](i32x8 (&b)[2], int slot) {
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+      const i32x4 lo = *(const i32x4*)(smem + slot * kHalfBytes + b_off[0] + nb * 2048);
+      const i32x4 hi = *(const i32x4*)(smem + slot * kHalfBytes + b_off[1] + nb * 2048);
+      b[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x8 a[4], bp[2], bq[2];
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // Prologue: half-tiles 0..4 (all of K-tile 0 and B-lo of K-tile 1) in flight, 0 and 1 landed.
+  issue(I0{}, I0{}, 0);
+  issue(I1{}, I0{}, 0);
+  issue(I2{}, I0{}, 0);
+  issue(I3{}, I0{}, 0);
+  issue(I0{}, I1{}, 1);
+  wait_vmcnt<6>();
+  GMD_PHASE_FENCE();
+  read_b(bp, 0);  // B-lo of K-tile 0
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (wr == 1) { GMD_PHASE_FENCE(); }  // run the second wave row one barrier behind the first
+
+  // One phase.  P: phase within a pair of K-tiles (0..7).  TAIL: last pair, where issue stops and the waits shrink.
+  auto phase = [&](auto PH, auto TAILF, int kt0) {
+    constexpr int P = decltype(PH)::value;
+    constexpr bool TAIL = decltype(TAILF)::value != 0;
+    constexpr int par = P >> 2, p = P & 3;  // parity of the K-tile this phase computes on
+    // -- reads (half-tile P+1 of the pair) --
+    if constexpr (p == 0) read_a(a, par * 4 + 1);
+    else if constexpr (p == 1) read_b(par ? bp : bq, par * 4 + 2);
+    else if constexpr (p == 2) read_a(a, par * 4 + 3);
+    else if constexpr (!(TAIL && P == 7)) read_b(par ? bp : bq, (par ^ 1) * 4 + 0);
+    // -- issue half-tile P+5 of the pair, i.e. kind (P+5)&3 of K-tile kt0 + (P+5)/4 --
+    constexpr int J = P + kAhead;
+    if constexpr (!(TAIL && J >= 8)) {
+      issue(std::integral_constant<int, (J & 3)>{}, std::integral_constant<int, ((J >> 2) & 1)>{}, kt0 + (J >> 2));
+      wait_vmcnt<2 * (kAhead - 2)>();
+    } else if constexpr (P == 3) {
+      wait_vmcnt<4>();
+    } else if constexpr (P == 4) {
+      wait_vmcnt<2>();
+    } else if constexpr (P == 5) {
+      wait_vmcnt<0>();
+    }
+    GMD_PHASE_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+    // -- MFMAs of quadrant p: (m-lo,n-lo) (m-lo,n-hi) (m-hi,n-hi) (m-hi,n-lo); B-lo sits in bp on even K-tiles, bq on odd --
+    if constexpr (p == 0) quadrant<0, 0, DT>(acc, a, par ? bq : bp);
+    else if constexpr (p == 1) quadrant<0, 2, DT>(acc, a, par ? bp : bq);
+    else if constexpr (p == 2) quadrant<4, 2, DT>(acc, a, par ? bp : bq);
+    else quadrant<4, 0, DT>(acc, a, par ? bq : bp);
+    __builtin_amdgcn_s_setprio(0);
+    GMD_PHASE_FENCE();
+  };
+
+  const int npairs = (int)(row_bytes / BKB) >> 1;
+  using F = std::integral_constant<int, 0>;
+  using T = std::integral_constant<int, 1>;
+  for (int it = 0; it + 1 < npairs; it++) {
+    const int kt0 = 2 * it;
+    phase(std::integral_constant<int, 0>{}, F{}, kt0);
+    phase(std::integral_constant<int, 1>{}, F{}, kt0);
+    phase(std::integral_constant<int, 2>{}, F{}, kt0);
+    phase(std::integral_constant<int, 3>{}, F{}, kt0);
+    phase(std::integral_constant<int, 4>{}, F{}, kt0);
+    phase(std::integral_constant<int, 5>{}, F{}, kt0);
+    phase(std::integral_constant<int, 6>{}, F{}, kt0);
+    phase(std::integral_constant<int, 7>{}, F{}, kt0);
+  }
+  {
+    const int kt0 = 2 * (npairs - 1);
+    phase(std::integral_constant<int, 0>{}, T{}, kt0);
+    phase(std::integral_constant<int, 1>{}, T{}, kt0);
+    phase(std::integral_constant<int, 2>{}, T{}, kt0);
+    phase(std::integral_constant<int, 3>{}, T{}, kt0);
+    phase(std::integral_constant<int, 4>{}, T{}, kt0);
+    phase(std::integral_constant<int, 5>{}, T{}, kt0);
+    phase(std::integral_constant<int, 6>{}, T{}, kt0);
+    phase(std::integral_constant<int, 7>{}, T{}, kt0);
+  }
+  if (wr == 0) { GMD_PHASE_FENCE(); }  // the barrier the second wave row took up front
+
+  const int m0 = tm * BM + wr * 128 + fr;
+  const int n0 = tn * BN + wc * 64 + fq * 4;
+#pragma unroll
+  for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) {
+      bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
+      *(bf16x4*)(C + (size_t)(m0 + mb * 16) * N + n0 + nb * 16) = o;
+    }
+}
+
 // ---- output checksum (integer, order-independent -> bitwise reproducible) ----
 __global__ void checksum_kernel(const uint4* __restrict__ c, uint64_t n16, unsigned long long* out) {
   unsigned long long s = 0;
@@ -331,15 +577,32 @@ double peak_flops_per_mfma(int dt) {
   }
 }
 
+// Which GEMM schedule runs: 1 = phase-interleaved pipeline (default), 0 = the simple
+// double-buffered loop (kept as the A/B baseline and for odd K-tile counts).
+int g_gemm_variant = -1;
+
+int gemm_variant() {
+  if (g_gemm_variant < 0) {
+    const char* e = getenv("GMD_GEMM_VARIANT");
+    g_gemm_variant = e && *e ? atoi(e) : 1;
+  }
+  return g_gemm_variant;
+}
+
 template <int DT>
 int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t row_bytes, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     GMD_HIP(hipFuncSetAttribute((const void*)gemm_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     attr_set = true;
   }
   const int grid = (m / BM) * (n / BN);
-  gemm_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+  const size_t ktiles = row_bytes / BKB;
+  if (gemm_variant() == 1 && ktiles >= 2 && (ktiles & 1) == 0)
+    gemm_pp_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+  else
+    gemm_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
   GMD_HIP(hipGetLastError());
   return GMD_OK;
 }
@@ -347,6 +610,12 @@ int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t ro
 }  // namespace
 
 extern "C" {
+
+int gmd_gemm_set_variant(int variant) {
+  if (variant < 0 || variant > 1) return GMD_ERR_BADPARAM;
+  g_gemm_variant = variant;
+  return GMD_OK;
+}
 
 int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream) {
   if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || (m % BM) || (n % BN)) return GMD_ERR_BADPARAM;

@@ -186,6 +186,13 @@ def gemm_stress(dtype="bf16", m=8192, n=8192, k=8192, seconds=2.0, verify=True, 
     return _dict(r)
 
 
+def gemm_set_variant(variant):
+    """1 = phase-interleaved pipeline (default), 0 = simple double-buffered loop (A/B baseline)."""
+    rc = _lib().gmd_gemm_set_variant(int(variant))
+    if rc:
+        raise DiagError(rc, "gmd_gemm_set_variant")
+
+
 COLLECTIVES = {"all_reduce": 0, "all_gather": 1, "reduce_scatter": 2, "all_to_all": 3, "broadcast": 4}
 
 
