@@ -57,6 +57,13 @@ $(BUILD)/bin/gpumon-diag: cmd/gpumon-diag.cc cmd/cli_common.h diag/gpumon_diag.h
 	$(CXX) $(CXXFLAGS) -fvisibility=default -o $@ $< -L$(BUILD) -lgpumon_diag -lgpumon \
 	    -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath-link,$(ROCM)/lib $(LDFLAGS)
 
+# Timing-only ablation builds of the GEMM pipeline (fragment reads / DMA / MFMAs
+# removed one at a time); used by scripts/gpu_gemm_ablate.py, never by the product.
+diag-ablate: $(BUILD)/libgpumon_diag_ablate.so
+$(BUILD)/libgpumon_diag_ablate.so: $(DIAG_HIP) diag/gpumon_diag.h diag/hip/diag_common.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -DGMD_GEMM_ABLATE -shared -o $@ $(DIAG_HIP) -ldl
+
 # ---- tests -------------------------------------------------------------------
 TESTS := $(patsubst tests/cpp/%.cc,$(BUILD)/tests/%,$(wildcard tests/cpp/*.cc))
 $(BUILD)/tests/%: tests/cpp/%.cc $(BUILD)/libgpumon.so

@@ -199,26 +199,29 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restric
 // one C quadrant (64x32 of the wave's 128x64) each:
 //
 //     [ds_read the fragments this or the next phase needs] [issue one half-tile of
-//     LDS-DMA] [s_waitcnt vmcnt(6)]  s_barrier  [16 MFMA (8 for MX-fp8)]  s_barrier
+//     LDS-DMA] [s_waitcnt vmcnt(10)]  s_barrier  [16 MFMA (8 for MX-fp8)]  s_barrier
 //
 // * Operand tiles are staged in half-tiles of 128 rows x 128 B (16 KiB, two
 //   LDS-DMA instructions per wave), in the order the phases consume them:
 //   B-lo, A-lo, B-hi, A-hi of K-tile 0, B-lo of K-tile 1, ...  ("lo"/"hi" = the
 //   rows that the first / second quadrant pair of every wave reads).  Half-tile j
 //   is read in phase j-1 and lives in ring slot j % 8 (128 KiB in all).
-// * Phase q issues half-tile q+5 and then waits until at most three half-tiles
-//   (6 instructions) are outstanding, which retires half-tile q+2: everything a
+// * Phase q issues half-tile q+7 and then waits until at most five half-tiles
+//   (10 instructions) are outstanding, which retires half-tile q+2: everything a
 //   phase reads was waited for one phase earlier, by every wave, before a barrier
 //   the reader has passed.  The loop never drains to vmcnt(0).
-// * A slot is overwritten five phases... by half-tile j+8, issued in phase j+3,
-//   four phases after its last read.
+// * Slot j % 8 is overwritten by half-tile j+8, issued in phase j+1: two phases
+//   after the slot's only read, the margin the one-barrier stagger of the two
+//   wave rows needs.  (Issue distances 5, 6 and 7 measure within 2 % of each
+//   other at 8192^3; what bounds the kernel is shown by `make diag-ablate`:
+//   the LDS-DMA stream alone and the MFMAs alone each take ~75 % of the full time.)
 // * The two wave rows (wr = 0 / 1) share each SIMD and run one barrier apart, so
 //   while one row issues its MFMAs the other row issues its LDS reads and DMA:
 //   8 ds_read_b128 x 4 waves take the LDS pipe about as long as 16 MFMAs take the
 //   matrix pipe.  The B-lo fragments of the next K-tile are read into whichever
 //   B register set is idle, which makes the per-phase read counts 8 / 4 / 8 / 4.
 constexpr int kHalfBytes = 128 * BKB;  // one ring slot
-constexpr int kAhead = 5;              // half-tiles issued ahead of the running phase
+constexpr int kAheadDefault = 7;       // issue distance in half-tiles (5..7 with the 8-slot ring)
 
 // Tile order: XCD-contiguous chunks (as above), walked in column-major groups of
 // four tile rows, so the ~32 tiles an XCD has in flight form a 4 x 8 block that
@@ -270,9 +273,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_barrier();            \
   __builtin_amdgcn_sched_barrier(0)
 
-template <int DT>
+// ABL is for timing-only ablation builds (make diag-ablate; results are wrong by design):
+// bit 0 drops the fragment reads of the loop, bit 1 the LDS-DMA and its waits, bit 2 the MFMAs.
+template <int DT, int ABL = 0, int AHEAD = kAheadDefault>
 __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+  constexpr int kAhead = AHEAD;  // half-tiles issued ahead of the running phase; kAhead - 2 of them are in flight
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -346,19 +352,27 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   i32x8 a[4], bp[2], bq[2];
+  if constexpr (ABL & 1) {  // the loop never loads them: give them defined contents
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = i32x8{lane, 1, 2, 3, 4, 5, 6, 7};
+    bq[0] = bq[1] = i32x8{7, 6, 5, 4, 3, 2, 1, lane};
+  }
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
 
-  // Prologue: half-tiles 0..4 (all of K-tile 0 and B-lo of K-tile 1) in flight, 0 and 1 landed.
+  // Prologue: half-tiles 0..kAhead-1 in flight (all of K-tile 0 and the start of K-tile 1), 0 and 1 landed.
+  static_assert(kAhead >= 5 && kAhead <= 7, "ring of 8 slots: 2 phases of read-to-overwrite margin need kAhead <= 7");
   issue(I0{}, I0{}, 0);
   issue(I1{}, I0{}, 0);
   issue(I2{}, I0{}, 0);
   issue(I3{}, I0{}, 0);
   issue(I0{}, I1{}, 1);
-  wait_vmcnt<6>();
+  if constexpr (kAhead > 5) issue(I1{}, I1{}, 1);
+  if constexpr (kAhead > 6) issue(I2{}, I1{}, 1);
+  wait_vmcnt<2 * (kAhead - 2)>();
   GMD_PHASE_FENCE();
   read_b(bp, 0);  // B-lo of K-tile 0
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -370,27 +384,32 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
     constexpr bool TAIL = decltype(TAILF)::value != 0;
     constexpr int par = P >> 2, p = P & 3;  // parity of the K-tile this phase computes on
     // -- reads (half-tile P+1 of the pair) --
-    if constexpr (p == 0) read_a(a, par * 4 + 1);
-    else if constexpr (p == 1) read_b(par ? bp : bq, par * 4 + 2);
-    else if constexpr (p == 2) read_a(a, par * 4 + 3);
-    else if constexpr (!(TAIL && P == 7)) read_b(par ? bp : bq, (par ^ 1) * 4 + 0);
+    if constexpr (!(ABL & 1)) {
+      if constexpr (p == 0) read_a(a, par * 4 + 1);
+      else if constexpr (p == 1) read_b(par ? bp : bq, par * 4 + 2);
+      else if constexpr (p == 2) read_a(a, par * 4 + 3);
+      else if constexpr (!(TAIL && P == 7)) read_b(par ? bp : bq, (par ^ 1) * 4 + 0);
+    }
     // -- issue half-tile P+5 of the pair, i.e. kind (P+5)&3 of K-tile kt0 + (P+5)/4 --
     constexpr int J = P + kAhead;
-    if constexpr (!(TAIL && J >= 8)) {
+    if constexpr (ABL & 2) {
+    } else if constexpr (!(TAIL && J >= 8)) {
       issue(std::integral_constant<int, (J & 3)>{}, std::integral_constant<int, ((J >> 2) & 1)>{}, kt0 + (J >> 2));
       wait_vmcnt<2 * (kAhead - 2)>();
-    } else if constexpr (P == 3) {
-      wait_vmcnt<4>();
-    } else if constexpr (P == 4) {
-      wait_vmcnt<2>();
-    } else if constexpr (P == 5) {
-      wait_vmcnt<0>();
+    } else if constexpr (P <= 5) {
+      // Last pair, nothing left to issue: half-tile P+2 must land, 7-(P+2) half-tiles may still fly.
+      wait_vmcnt<2 * (5 - P)>();
     }
     GMD_PHASE_FENCE();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(1);
     // -- MFMAs of quadrant p: (m-lo,n-lo) (m-lo,n-hi) (m-hi,n-hi) (m-hi,n-lo); B-lo sits in bp on even K-tiles, bq on odd --
-    if constexpr (p == 0) quadrant<0, 0, DT>(acc, a, par ? bq : bp);
+    if constexpr (ABL & 4) {  // keep what the MFMAs would have consumed alive
+#pragma unroll
+      for (int i = 0; i < 4; i++) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+      for (int i = 0; i < 2; i++) asm volatile("" ::"v"(bp[i]), "v"(bq[i]));
+    } else if constexpr (p == 0) quadrant<0, 0, DT>(acc, a, par ? bq : bp);
     else if constexpr (p == 1) quadrant<0, 2, DT>(acc, a, par ? bp : bq);
     else if constexpr (p == 2) quadrant<4, 2, DT>(acc, a, par ? bp : bq);
     else quadrant<4, 0, DT>(acc, a, par ? bq : bp);
@@ -599,6 +618,48 @@ int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t ro
   }
   const int grid = (m / BM) * (n / BN);
   const size_t ktiles = row_bytes / BKB;
+#ifdef GMD_GEMM_ABLATE
+  // variants 10 + mask: timing-only builds of the pipeline with parts removed
+#define GMD_ABL_CASE(MASK)                                                                                             \
+  case 10 + MASK: {                                                                                                    \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  kLdsBytes));                                                                         \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    gemm_pp_kernel<DT, MASK><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n,      \
+                                                                 row_bytes);                                           \
+    GMD_HIP(hipGetLastError());                                                                                        \
+    return GMD_OK;                                                                                                     \
+  }
+#define GMD_AHEAD_CASE(D)                                                                                              \
+  case 20 + D: {                                                                                                       \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  kLdsBytes));                                                                         \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    gemm_pp_kernel<DT, 0, D><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n,      \
+                                                                 row_bytes);                                           \
+    GMD_HIP(hipGetLastError());                                                                                        \
+    return GMD_OK;                                                                                                     \
+  }
+  switch (gemm_variant()) {
+    GMD_AHEAD_CASE(5)
+    GMD_AHEAD_CASE(6)
+    GMD_AHEAD_CASE(7)
+    GMD_ABL_CASE(1)
+    GMD_ABL_CASE(2)
+    GMD_ABL_CASE(3)
+    GMD_ABL_CASE(4)
+    GMD_ABL_CASE(5)
+    GMD_ABL_CASE(6)
+    GMD_ABL_CASE(7)
+    default: break;
+  }
+#endif
   if (gemm_variant() == 1 && ktiles >= 2 && (ktiles & 1) == 0)
     gemm_pp_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
   else
@@ -612,6 +673,12 @@ int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t ro
 extern "C" {
 
 int gmd_gemm_set_variant(int variant) {
+#ifdef GMD_GEMM_ABLATE
+  if ((variant >= 11 && variant <= 17) || (variant >= 25 && variant <= 27)) {
+    g_gemm_variant = variant;
+    return GMD_OK;
+  }
+#endif
   if (variant < 0 || variant > 1) return GMD_ERR_BADPARAM;
   g_gemm_variant = variant;
   return GMD_OK;

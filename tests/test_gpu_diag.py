@@ -179,6 +179,34 @@ def test_gemm_matches_fp32_reference(diag, dev, dtype, shape):
     assert torch.equal(c2, c[perm])
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "mxfp8"])
+def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
+    """The pipelined schedule and the simple double-buffered loop add the same products in the same
+    order, so their outputs are identical; repeated launches of the pipeline must not differ either
+    (a race between LDS-DMA and fragment reads would show as run-to-run differences).  An odd number
+    of K-tiles takes the fallback path."""
+    try:
+        for (m, n, k) in [(512, 512, 2048), (1024, 768, 8192), (256, 256, 128 * 3 if dtype == "mxfp8" else 64 * 3)]:
+            a, b = _gemm_inputs(dev, m, n, k, dtype, seed=k)
+            outs = {}
+            for variant in (0, 1):
+                diag.gemm_set_variant(variant)
+                c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+                diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, _stream())
+                torch.cuda.synchronize()
+                outs[variant] = c
+            assert torch.equal(outs[0], outs[1]), (m, n, k)
+            c = torch.empty_like(outs[1])
+            for _ in range(20):
+                diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, _stream())
+            torch.cuda.synchronize()
+            assert torch.equal(c, outs[1])
+        with pytest.raises(diag.DiagError):
+            diag.gemm_set_variant(9)
+    finally:
+        diag.gemm_set_variant(1)
+
+
 def test_gemm_rejects_shapes_the_tiling_cannot_cover(diag, dev):
     x = torch.zeros(512, 512, dtype=torch.bfloat16, device=dev)
     for m, n, k in [(500, 512, 512), (512, 384 + 1, 512), (512, 512, 96), (0, 512, 512)]:
