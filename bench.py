@@ -17,6 +17,10 @@ read from /proc over the timed window.
 headline numbers (HBM TB/s, MX-fp8 TFLOPS, RCCL bus bandwidth, scrape p50,
 exporter CPU %) are in `extras`.  Nothing is skipped in the timed region and
 per-phase times come from HIP events on the stream the phases run on.
+
+`--dry-run` exercises the same control flow (rank handling, collectives, the
+reductions, the JSON) on CPU tensors over gloo with toy sizes; it exists so the
+multi-rank path can be tested without GPUs and its output is labelled as such.
 """
 import argparse
 import json
@@ -34,20 +38,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-GEMM_DIM = 8192
-HBM_BYTES = 4 << 30
-COLL_BYTES = 1 << 30
 MEMTEST_PATTERN = "random"
+
+
+class Sizes:
+    def __init__(self, dry):
+        self.gemm_dim = 256 if dry else 8192
+        self.hbm_bytes = (1 << 20) if dry else (4 << 30)
+        self.coll_bytes = (1 << 20) if dry else (1 << 30)
 
 
 class ExporterChild:
     """gpumon-exporter as a child process (started before this process touches the GPU)."""
 
-    def __init__(self):
+    def __init__(self, backend="amdsmi"):
         from k8s_gpu_monitor_amd._lib import binary
+        env = dict(os.environ, GPUMON_BACKEND=backend)
+        if backend == "fake":
+            env.setdefault("GPUMON_BACKEND_SPEC", "gpus=8,seed=1")
         self.proc = subprocess.Popen(
             [binary("gpumon-exporter"), "-e", "-p", "-o", "", "-d", "1000", "--extras", "--self-metrics", "--listen",
-             "127.0.0.1:0"], stderr=subprocess.PIPE, text=True, env=dict(os.environ, GPUMON_BACKEND="amdsmi"))
+             "127.0.0.1:0"], stderr=subprocess.PIPE, text=True, env=env)
         self.port = None
         self.log = []
         deadline = time.time() + 60
@@ -104,6 +115,123 @@ class ExporterChild:
                 self.proc.kill()
 
 
+class GpuKernels:
+    """The seven compute phases on one MI355X: libgpumon_diag kernels on torch-owned buffers."""
+
+    def __init__(self, torch, dev, sz, G, rank):
+        from k8s_gpu_monitor_amd.ops import diag
+        self.torch, self.diag, self.dev, self.sz, self.G = torch, diag, dev, sz, G
+        self.stream = torch.cuda.current_stream(dev)
+        self.sptr = self.stream.cuda_stream
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        D = sz.gemm_dim
+        self.nf = sz.hbm_bytes // 4
+        self.ha = torch.empty(self.nf, dtype=torch.float32, device=dev).normal_(generator=g)
+        self.hb = torch.empty(self.nf, dtype=torch.float32, device=dev).normal_(generator=g)
+        self.hc = torch.empty(self.nf, dtype=torch.float32, device=dev)
+        self.sink = torch.zeros(1 << 16, dtype=torch.float32, device=dev)
+        self.A16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev).normal_(generator=g)
+        self.B16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev).normal_(generator=g)
+        self.C16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev)
+        self.A8 = torch.empty(D, D, dtype=torch.float32, device=dev).normal_(generator=g).to(torch.float8_e4m3fn)
+        self.B8 = torch.empty(D, D, dtype=torch.float32, device=dev).normal_(generator=g).to(torch.float8_e4m3fn)
+        self.C8 = torch.empty(D, D, dtype=torch.bfloat16, device=dev)
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def record(self, e):
+        e.record(self.stream)
+
+    def elapsed_ms(self, e0, e1):
+        return e0.elapsed_time(e1)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def comm_tensor(self, n):
+        g = self.torch.Generator(device=self.dev).manual_seed(99)
+        return self.torch.empty(n, dtype=self.torch.bfloat16, device=self.dev).normal_(generator=g)
+
+    def hbm_read(self):
+        self.diag.hbm_stream_launch("read", self.ha.data_ptr(), 0, self.sink.data_ptr(), 0.0, self.nf, "auto", self.sptr)
+
+    def hbm_write(self):
+        self.diag.hbm_stream_launch("write", self.hc.data_ptr(), 0, 0, 1.5, self.nf, "auto", self.sptr)
+
+    def hbm_copy(self):
+        self.diag.hbm_stream_launch("copy", self.ha.data_ptr(), 0, self.hc.data_ptr(), 0.0, self.nf, "auto", self.sptr)
+
+    def hbm_triad(self):
+        self.diag.hbm_stream_launch("triad", self.ha.data_ptr(), self.hb.data_ptr(), self.hc.data_ptr(), 0.5, self.nf, "auto",
+                                    self.sptr)
+
+    def memtest(self, i):
+        self.diag.memtest_fill(self.hc.data_ptr(), self.sz.hbm_bytes // 8, MEMTEST_PATTERN, seed=i, stream=self.sptr)
+        errs, _ = self.diag.memtest_verify(self.hc.data_ptr(), self.sz.hbm_bytes // 8, MEMTEST_PATTERN, seed=i, stream=self.sptr)
+        return errs
+
+    def gemm_bf16(self):
+        D = self.sz.gemm_dim
+        for _ in range(self.G):
+            self.diag.gemm_launch("bf16", self.A16.data_ptr(), self.B16.data_ptr(), self.C16.data_ptr(), D, D, D, self.sptr)
+
+    def gemm_mxfp8(self):
+        D = self.sz.gemm_dim
+        for _ in range(self.G):
+            self.diag.gemm_launch("mxfp8", self.A8.data_ptr(), self.B8.data_ptr(), self.C8.data_ptr(), D, D, D, self.sptr)
+
+
+class DryKernels:
+    """CPU stand-ins with the same interface (toy sizes): for testing the control flow only."""
+
+    class _Ev:
+        t = 0.0
+
+    def __init__(self, torch, dev, sz, G, rank):
+        self.torch, self.dev, self.sz, self.G = torch, dev, sz, G
+        D = sz.gemm_dim
+        self.x = torch.randn(sz.hbm_bytes // 4)
+        self.y = torch.randn(sz.hbm_bytes // 4)
+        self.a = torch.randn(D, D)
+
+    def event(self):
+        return DryKernels._Ev()
+
+    def record(self, e):
+        e.t = time.perf_counter()
+
+    def elapsed_ms(self, e0, e1):
+        return max((e1.t - e0.t) * 1e3, 1e-6)
+
+    def sync(self):
+        pass
+
+    def comm_tensor(self, n):
+        return self.torch.randn(n)  # fp32: gloo's reductions do not cover bf16 on every build
+
+    def hbm_read(self):
+        self.x.sum()
+
+    def hbm_write(self):
+        self.y.fill_(1.5)
+
+    def hbm_copy(self):
+        self.y.copy_(self.x)
+
+    def hbm_triad(self):
+        self.torch.add(self.x, self.y, alpha=0.5, out=self.y)
+
+    def memtest(self, i):
+        return 0
+
+    def gemm_bf16(self):
+        for _ in range(self.G):
+            self.a @ self.a
+
+    gemm_mxfp8 = gemm_bf16
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +239,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gemm-launches", type=int, default=8, help="GEMM launches per dtype per step")
     ap.add_argument("--no-exporter", action="store_true", help="debug: skip the exporter child and the scrape phase")
+    ap.add_argument("--dry-run", action="store_true", help="CPU + gloo + fake backend with toy sizes: control-flow test only")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -124,21 +253,28 @@ def main():
 
     exporter = None
     if rank == 0 and not a.no_exporter:
-        exporter = ExporterChild()  # before any HIP call in this process
+        exporter = ExporterChild("fake" if a.dry_run else "amdsmi")  # before any HIP call in this process
 
     import torch
     import torch.distributed as dist
-    from k8s_gpu_monitor_amd.ops import diag
     from k8s_gpu_monitor_amd.parallel.collectives import busbw_factor
 
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    sz = Sizes(a.dry_run)
+    if a.dry_run:
+        dev = torch.device("cpu")
+        backend, kw = "gloo", {}
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        backend, kw = "nccl", {"device_id": dev}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     try:
-        result = run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor)
+        kernels = (DryKernels if a.dry_run else GpuKernels)(torch, dev, sz, a.gemm_launches, rank)
+        result = run(a, world, dev, exporter, torch, dist, kernels, sz, busbw_factor)
     finally:
         if exporter:
             exporter.stop()
@@ -148,68 +284,48 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-def run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor):
-    G, D = a.gemm_launches, GEMM_DIM
-    stream = torch.cuda.current_stream(dev)
-    sptr = stream.cuda_stream
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-
-    # ---- buffers (resident for the whole run) ----
-    nf = HBM_BYTES // 4
-    ha = torch.empty(nf, dtype=torch.float32, device=dev).normal_(generator=g)
-    hb = torch.empty(nf, dtype=torch.float32, device=dev).normal_(generator=g)
-    hc = torch.empty(nf, dtype=torch.float32, device=dev)
-    sink = torch.zeros(1 << 16, dtype=torch.float32, device=dev)
-    A16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev).normal_(generator=g)
-    B16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev).normal_(generator=g)
-    C16 = torch.empty(D, D, dtype=torch.bfloat16, device=dev)
-    A8 = torch.empty(D, D, dtype=torch.float32, device=dev).normal_(generator=g).to(torch.float8_e4m3fn)
-    B8 = torch.empty(D, D, dtype=torch.float32, device=dev).normal_(generator=g).to(torch.float8_e4m3fn)
-    C8 = torch.empty(D, D, dtype=torch.bfloat16, device=dev)
+def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
+    G, D = a.gemm_launches, sz.gemm_dim
     if world > 1:
-        ne = COLL_BYTES // 2
-        ar = torch.empty(ne, dtype=torch.bfloat16, device=dev).normal_(generator=g)
+        ne = sz.coll_bytes // 2
+        ar = K.comm_tensor(ne)
         ag_in = ar[: ne // world]
-        ag_out = torch.empty(ne, dtype=torch.bfloat16, device=dev)
-        a2a_out = torch.empty(ne, dtype=torch.bfloat16, device=dev)
+        ag_out = torch.empty(ne, dtype=ar.dtype, device=dev)
+        a2a_out = torch.empty(ne, dtype=ar.dtype, device=dev)
 
     phases = ["hbm_read", "hbm_write", "hbm_copy", "hbm_triad", "memtest", "gemm_bf16", "gemm_mxfp8"]
     if world > 1:
         phases += ["all_reduce", "all_gather", "all_to_all"]
     total_steps = a.warmup + a.steps
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(phases) + 1)] for _ in range(total_steps)]
-    scrape_ms, memtest_errors, scrape_bytes = [], 0, 0
+    ev = [[K.event() for _ in range(len(phases) + 1)] for _ in range(total_steps)]
+    scrape_ms, scrape_bytes = [], 0
+    memtest_errors = 0
 
     def step(i):
         nonlocal memtest_errors, scrape_bytes
         e = ev[i]
-        k = 0
-        e[k].record(stream)
-        diag.hbm_stream_launch("read", ha.data_ptr(), 0, sink.data_ptr(), 0.0, nf, "auto", sptr)
-        k += 1; e[k].record(stream)
-        diag.hbm_stream_launch("write", hc.data_ptr(), 0, 0, 1.5, nf, "auto", sptr)
-        k += 1; e[k].record(stream)
-        diag.hbm_stream_launch("copy", ha.data_ptr(), 0, hc.data_ptr(), 0.0, nf, "auto", sptr)
-        k += 1; e[k].record(stream)
-        diag.hbm_stream_launch("triad", ha.data_ptr(), hb.data_ptr(), hc.data_ptr(), 0.5, nf, "auto", sptr)
-        k += 1; e[k].record(stream)
-        diag.memtest_fill(hc.data_ptr(), HBM_BYTES // 8, MEMTEST_PATTERN, seed=i, stream=sptr)
-        errs, _ = diag.memtest_verify(hc.data_ptr(), HBM_BYTES // 8, MEMTEST_PATTERN, seed=i, stream=sptr)
-        memtest_errors += errs
-        k += 1; e[k].record(stream)
-        for _ in range(G):
-            diag.gemm_launch("bf16", A16.data_ptr(), B16.data_ptr(), C16.data_ptr(), D, D, D, sptr)
-        k += 1; e[k].record(stream)
-        for _ in range(G):
-            diag.gemm_launch("mxfp8", A8.data_ptr(), B8.data_ptr(), C8.data_ptr(), D, D, D, sptr)
-        k += 1; e[k].record(stream)
+        K.record(e[0])
+        K.hbm_read()
+        K.record(e[1])
+        K.hbm_write()
+        K.record(e[2])
+        K.hbm_copy()
+        K.record(e[3])
+        K.hbm_triad()
+        K.record(e[4])
+        memtest_errors += K.memtest(i)
+        K.record(e[5])
+        K.gemm_bf16()
+        K.record(e[6])
+        K.gemm_mxfp8()
+        K.record(e[7])
         if world > 1:
             dist.all_reduce(ar)
-            k += 1; e[k].record(stream)
+            K.record(e[8])
             dist.all_gather_into_tensor(ag_out, ag_in)
-            k += 1; e[k].record(stream)
+            K.record(e[9])
             dist.all_to_all_single(a2a_out, ar)
-            k += 1; e[k].record(stream)
+            K.record(e[10])
             if i % 8 == 7:  # keep the all-reduced values bounded
                 ar.mul_(1.0 / world ** 8)
         if exporter is not None:
@@ -219,9 +335,10 @@ def run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor):
                 scrape_bytes = len(body)
 
     def fence():
+        K.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        K.sync()
 
     for i in range(a.warmup):
         step(i)
@@ -238,18 +355,18 @@ def run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor):
     ph_ms = torch.zeros(len(phases), dtype=torch.float64)
     for i in range(a.warmup, total_steps):
         for k in range(len(phases)):
-            ph_ms[k] += ev[i][k].elapsed_time(ev[i][k + 1])
+            ph_ms[k] += K.elapsed_ms(ev[i][k], ev[i][k + 1])
     ph_ms /= a.steps
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ph_dev = ph_ms.to(dev)
-    ph_max = ph_dev.clone()
+    ph_max = ph_ms.to(dev).clone()
     errs_t = torch.tensor([memtest_errors], dtype=torch.int64, device=dev)
     gemm_flops = 2.0 * D * D * D * G
-    # per-rank rates, summed over ranks = the job's aggregate
+    hb = sz.hbm_bytes
+    # per-rank rates; summed over ranks = the job's aggregate
     rates = torch.tensor([gemm_flops / (ph_ms[5].item() * 1e-3) / 1e12, gemm_flops / (ph_ms[6].item() * 1e-3) / 1e12,
-                          HBM_BYTES / (ph_ms[0].item() * 1e-3) / 1e12, HBM_BYTES / (ph_ms[1].item() * 1e-3) / 1e12,
-                          2 * HBM_BYTES / (ph_ms[2].item() * 1e-3) / 1e12, 3 * HBM_BYTES / (ph_ms[3].item() * 1e-3) / 1e12,
-                          2 * HBM_BYTES / (ph_ms[4].item() * 1e-3) / 1e12], dtype=torch.float64, device=dev)
+                          hb / (ph_ms[0].item() * 1e-3) / 1e12, hb / (ph_ms[1].item() * 1e-3) / 1e12,
+                          2 * hb / (ph_ms[2].item() * 1e-3) / 1e12, 3 * hb / (ph_ms[3].item() * 1e-3) / 1e12,
+                          2 * hb / (ph_ms[4].item() * 1e-3) / 1e12], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
@@ -274,7 +391,7 @@ def run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor):
     }
     if world > 1:
         for k, op in ((7, "all_reduce"), (8, "all_gather"), (9, "all_to_all")):
-            alg = COLL_BYTES / (ph_max[k].item() * 1e-3) / 1e9
+            alg = sz.coll_bytes / (ph_max[k].item() * 1e-3) / 1e9
             extras[f"rccl_{op}_busbw_gbps"] = round(alg * busbw_factor(op, world), 1)
     if exporter is not None and scrape_ms:
         q = statistics.quantiles(scrape_ms, n=100) if len(scrape_ms) >= 2 else [scrape_ms[0]] * 99
@@ -289,9 +406,10 @@ def run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor):
         })
     if extras["memtest_errors"]:
         extras["FAILED"] = "memtest reported errors"
+    gib = lambda b: f"{b / 2**30:g}GiB"  # noqa: E731
     return {
         "metric": "diag_mfma_bf16_gemm_tflops",
-        "value": round(rates[0], 1),
+        "value": round(rates[0], 1 if not a.dry_run else 6),
         "unit": "TFLOP/s",
         "n_gpus": world,
         "steps": a.steps,
@@ -301,9 +419,11 @@ def run(a, rank, world, dev, exporter, torch, dist, diag, busbw_factor):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16",
-        "data": "synthetic (random normal operands, random-init buffers)",
+        "data": "DRY RUN on CPU (toy sizes, not a measurement)" if a.dry_run
+                else "synthetic (random normal operands, random-init buffers)",
         "config": {
-            "model": "gpumon diag suite: hbm stream 4GiB + memtest 4GiB + mfma gemm bf16/mxfp8 8192^3 + rccl 1GiB + exporter scrape @1s",
+            "model": f"gpumon diag suite: hbm stream {gib(sz.hbm_bytes)} + memtest {gib(sz.hbm_bytes)} + mfma gemm bf16/mxfp8 "
+                     f"{D}^3 + rccl {gib(sz.coll_bytes)} + exporter scrape @1s",
             "global_batch": G * world,
             "seq_len": D,
             "parallelism": f"dp{world}",
