@@ -392,7 +392,7 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
     if world > 1:
         for k, op in ((7, "all_reduce"), (8, "all_gather"), (9, "all_to_all")):
             alg = sz.coll_bytes / (ph_max[k].item() * 1e-3) / 1e9
-            extras[f"rccl_{op}_busbw_gbps"] = round(alg * busbw_factor(op, world), 1)
+            extras[f"rccl_{op}_busbw_gbps"] = round(alg * busbw_factor(op, world), 3)
     if exporter is not None and scrape_ms:
         q = statistics.quantiles(scrape_ms, n=100) if len(scrape_ms) >= 2 else [scrape_ms[0]] * 99
         extras.update({

@@ -10,13 +10,17 @@
 //   gpumon-diag rccl   [--gpus 0,1,..] [--ops a,b] [--min-bytes N] [--max-bytes N] [--scaling]
 //   gpumon-diag p2p    [--gpus 0,1,..] [--bytes N]
 //   gpumon-diag run -r 1|2|3 [-g GPU]      graded suites: quick / medium / long
-// Every command takes --json.  Exit status: 0 pass, 1 a test failed, 2 usage / setup error.
+// Every command takes --json and --publish FILE (leave the JSON report where
+// `gpumon-exporter --diag-results` picks it up and exports it as gpumon_diag_* metrics).
+// Exit status: 0 pass, 1 a test failed, 2 usage / setup error.
 #include <unistd.h>
 
 #include <strings.h>
 
+#include <cerrno>
 #include <cmath>
 #include <cstdarg>
+#include <ctime>
 #include <map>
 #include <thread>
 
@@ -48,7 +52,7 @@ struct Args {
 
 const char* kFlagsWithValue[] = {"-g", "--bytes", "--iters", "--kernel", "--min-tbps", "--fraction", "--patterns", "--passes",
                                  "--dtype", "--seconds", "--m", "--n", "--k", "--gpus", "--ops", "--min-bytes",
-                                 "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor"};
+                                 "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor", "--publish"};
 
 bool parse(const std::vector<std::string>& in, Args* a) {
   for (size_t i = 0; i < in.size(); i++) {
@@ -109,9 +113,24 @@ struct Report {
     fprintf(stderr, "\n");
     va_end(ap);
   }
-  int finish() {
-    if (json) printf("{%s,\"result\":\"%s\"}\n", js.c_str(), failed ? "fail" : "pass");
+  // The whole report as one JSON object; `gpu` and `timestamp` let the exporter label and age it.
+  std::string document(int gpu) const {
+    return "{\"gpu\":" + std::to_string(gpu) + ",\"timestamp\":" + std::to_string((long long)time(nullptr)) +
+           (js.empty() ? "" : "," + js) + ",\"result\":\"" + (failed ? "fail" : "pass") + "\"}";
+  }
+  int finish(int gpu, const std::string& publish_path) {
+    const std::string doc = document(gpu);
+    if (json) printf("%s\n", doc.c_str());
     else printf("\nResult: %s\n", failed ? "FAIL" : "PASS");
+    if (!publish_path.empty()) {
+      // temp + rename: the exporter never reads a half-written report
+      const std::string tmp = publish_path + ".swp";
+      FILE* f = fopen(tmp.c_str(), "w");
+      if (!f || fputs(doc.c_str(), f) < 0 || fclose(f) != 0 || rename(tmp.c_str(), publish_path.c_str()) != 0) {
+        fprintf(stderr, "error: cannot publish the report to %s: %s\n", publish_path.c_str(), strerror(errno));
+        return 2;
+      }
+    }
     return failed ? 1 : 0;
   }
 };
@@ -542,7 +561,8 @@ int cmd_run(const Args& a, Report& r) {
 
 void usage() {
   fprintf(stderr,
-          "usage: gpumon-diag <info|hbm|memtest|mfma|gemm|rccl|p2p|run> [options] [--json]\n"
+          "usage: gpumon-diag <info|hbm|memtest|mfma|gemm|rccl|p2p|run> [options] [--json] [--publish FILE]\n"
+          "  --publish FILE leaves the JSON report where `gpumon-exporter --diag-results` picks it up\n"
           "  hbm     [-g GPU] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
           "  memtest [-g GPU] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N]\n"
           "  mfma    [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
@@ -581,5 +601,5 @@ int main(int argc, char** argv) {
     return 2;
   }
   if (rc) return rc;
-  return r.finish();
+  return r.finish((int)a.num("-g", 0), a.str("--publish"));
 }

@@ -288,6 +288,7 @@ void Exporter::render(std::string* out) {
         }
   }
   if (cfg_.self_metrics) render_self(out);
+  if (!cfg_.diag_results_path.empty()) render_diag_results(cfg_.diag_results_path, out);
   last_render_us_ = monotonic_us() - t0;
 }
 

@@ -49,6 +49,7 @@ struct ExporterConfig {
   std::string kubelet_socket;
   std::string resource_names = "amd.com/gpu";
   std::string pod_map_path;
+  std::string diag_results_path;  // report(s) of gpumon-diag --publish, rendered as gpumon_diag_* families
 };
 
 class Exporter {
@@ -100,6 +101,8 @@ class Exporter {
 // REST routes of the reference's sample server (bindings/go/samples/dcgm/restApi/
 // server.go:40-71) under /dcgm/... with /gpumon/... aliases.  Returns false
 // when the path is not a REST route.
+// Appends the gpumon_diag_* families for the report file (or directory of *.json reports) at `path`.
+void render_diag_results(const std::string& path, std::string* out);
 bool handle_rest(Engine* engine, const HttpRequest& req, HttpResponse* resp);
 
 }  // namespace gpumon

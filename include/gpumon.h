@@ -679,8 +679,9 @@ typedef struct {
   const char* pod_map_path;   /* file-based pod map fallback (device-plugin checkpoint) */
   int32_t rest_api;         /* serve the REST routes on the same listener */
   int32_t legacy_layout;    /* 1 = GPU-major layout of the reference's awk script */
+  const char* diag_results_path; /* gpumon-diag --publish report (file, or directory of *.json): exported as gpumon_diag_* */
 } gm_exporter_config_t;
-#define GM_EXPORTER_CONFIG_VERSION GM_VERSION(gm_exporter_config_t, 1)
+#define GM_EXPORTER_CONFIG_VERSION GM_VERSION(gm_exporter_config_t, 2)
 
 typedef uint32_t gm_exporter_t;
 GM_API gm_status_t gm_exporter_create(const gm_exporter_config_t* cfg, gm_exporter_t* out);

@@ -270,3 +270,90 @@ def test_interval_floor_is_clamped_in_library(engine2):
     with E.Exporter(interval_ms=5) as ex:  # library clamps instead of failing
         ex.sweep()
         assert "dcgm_sm_clock" in ex.render()
+
+
+# ---- active-diagnostics reports as metrics ------------------------------------
+
+def _diag_report(gpu=1, result="pass", copy_tbps=5.5, errors=0):
+    """Same member names as `gpumon-diag run --json` writes."""
+    return {
+        "gpu": gpu, "timestamp": 1700000123,
+        "hbm_stream": {"read": {"tbps_best": 7.0, "tbps_median": 6.9, "verified": True},
+                       "copy": {"tbps_best": copy_tbps, "tbps_median": 5.4, "verified": True}},
+        "memtest": {"bytes_tested": 274877906944, "errors": errors},
+        "mfma_peak": {"bf16": {"tflops": 2179.5, "tflops_best": 2200.0}},
+        "gemm_stress": {"bf16": {"tflops": 1450.0, "tflops_best": 1500.0, "launches": 900, "sdc_mismatches": 0}},
+        "telemetry": {"power": {"min": 900.0, "avg": 1350.5, "max": 1400.0, "samples": 50},
+                      "gfx_clock": {"min": 2100.0, "avg": 2180.0, "max": 2400.0, "samples": 50}},
+        "rccl": {"gpus": 8, "points": [], "peak_busbw_gbps": {"all_reduce": 310.25, "all_gather": 295.0}},
+        "p2p_gbps": [[0, 48.5], [47.25, 0]],
+        "result": result,
+    }
+
+
+def _write_json(path, doc):
+    import json
+    tmp = str(path) + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(doc, f)
+    os.replace(tmp, path)
+
+
+def test_diag_report_becomes_metrics(engine2, tmp_path):
+    rep = tmp_path / "diag.json"
+    _write_json(rep, _diag_report())
+    with E.Exporter(diag_results_path=str(rep)) as ex:
+        ex.sweep()
+        fams = parse(ex.render())  # strict: HELP/TYPE once per family, well-formed labels
+        by = lambda fam: {tuple(sorted(l.items())): v for l, v in fams[fam].samples}
+        assert by("gpumon_diag_pass") == {(("gpu", "1"),): 1.0}
+        assert by("gpumon_diag_timestamp_seconds") == {(("gpu", "1"),): 1700000123.0}
+        assert by("gpumon_diag_hbm_stream_tbps")[(("gpu", "1"), ("kernel", "copy"))] == 5.5
+        assert by("gpumon_diag_hbm_stream_tbps")[(("gpu", "1"), ("kernel", "read"))] == 7.0
+        assert by("gpumon_diag_memtest_bytes") == {(("gpu", "1"),): 274877906944.0}
+        assert by("gpumon_diag_memtest_errors") == {(("gpu", "1"),): 0.0}
+        assert by("gpumon_diag_mfma_peak_tflops")[(("dtype", "bf16"), ("gpu", "1"))] == 2179.5
+        assert by("gpumon_diag_gemm_tflops")[(("dtype", "bf16"), ("gpu", "1"))] == 1450.0
+        assert by("gpumon_diag_gemm_sdc_mismatches")[(("dtype", "bf16"), ("gpu", "1"))] == 0.0
+        assert by("gpumon_diag_soak_power_watts")[(("gpu", "1"), ("stat", "avg"))] == 1350.5
+        assert by("gpumon_diag_soak_gfx_clock_mhz")[(("gpu", "1"), ("stat", "max"))] == 2400.0
+        assert "gpumon_diag_soak_gpu_temp_celsius" not in fams  # not in the report: no family
+        assert by("gpumon_diag_rccl_busbw_gbps")[(("gpus", "8"), ("op", "all_reduce"))] == 310.25
+        assert by("gpumon_diag_p2p_gbps") == {(("dst", "1"), ("src", "0")): 48.5, (("dst", "0"), ("src", "1")): 47.25}
+        assert "dcgm_sm_clock" in fams  # passive telemetry still there
+
+        # a newer report replaces the cached one
+        time.sleep(0.02)
+        _write_json(rep, _diag_report(result="fail", errors=3))
+        fams = parse(ex.render())
+        assert fams["gpumon_diag_pass"].samples[0][1] == 0.0
+        assert fams["gpumon_diag_memtest_errors"].samples[0][1] == 3.0
+
+
+def test_diag_report_directory_and_garbage(engine2, tmp_path):
+    d = tmp_path / "reports"
+    d.mkdir()
+    _write_json(d / "gpu0.json", _diag_report(gpu=0))
+    _write_json(d / "gpu1.json", _diag_report(gpu=1, result="fail"))
+    (d / "broken.json").write_text("{not json")
+    (d / "notes.txt").write_text("ignored")
+    with E.Exporter(diag_results_path=str(d)) as ex:
+        ex.sweep()
+        fams = parse(ex.render())
+        got = {l["gpu"]: v for l, v in fams["gpumon_diag_pass"].samples}
+        assert got == {"0": 1.0, "1": 0.0}
+    # a path that does not exist yet is not an error: the report may come later
+    with E.Exporter(diag_results_path=str(tmp_path / "later.json")) as ex:
+        ex.sweep()
+        assert "gpumon_diag_" not in ex.render()
+
+
+def test_exporter_cli_diag_results_flag(tmp_path):
+    rep = tmp_path / "diag.json"
+    _write_json(rep, _diag_report(gpu=0))
+    out = tmp_path / "metrics.prom"
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=2,steady=1")
+    r = subprocess.run([bin_path("gpumon-exporter"), "-e", "--once", "-o", str(out),
+                        "--diag-results", str(rep)], env=env, capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0, r.stderr
+    assert 'gpumon_diag_pass{gpu="0"} 1' in out.read_text()

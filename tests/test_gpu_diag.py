@@ -238,6 +238,28 @@ def test_rccl_sweep_single_gpu(diag):
         diag.rccl_sweep(devices=[0, 0])
 
 
+def test_cli_report_is_published_and_exported(tmp_path):
+    """gpumon-diag run -r 1 --publish -> gpumon-exporter --diag-results -> gpumon_diag_* series."""
+    import os
+    import subprocess
+    from conftest import bin_path
+    from k8s_gpu_monitor_amd.utils.promparse import parse
+    rep, out = tmp_path / "gpu0.json", tmp_path / "m.prom"
+    r = subprocess.run([bin_path("gpumon-diag"), "run", "-r", "1", "--publish", str(rep)],
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=1,steady=1")
+    r = subprocess.run([bin_path("gpumon-exporter"), "-e", "--once", "-o", str(out), "--diag-results", str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0, r.stderr
+    fams = parse(out.read_text())
+    assert fams["gpumon_diag_pass"].samples == [({"gpu": "0"}, 1.0)]
+    bw = {l["kernel"]: v for l, v in fams["gpumon_diag_hbm_stream_tbps"].samples}
+    assert bw["read"] > 4.0 and bw["copy"] > 3.5, bw
+    assert fams["gpumon_diag_memtest_errors"].samples[0][1] == 0
+    assert fams["gpumon_diag_memtest_bytes"].samples[0][1] == float(1 << 30)
+
+
 def test_torch_distributed_sweep_on_rccl(dev):
     import os
     import torch.distributed as dist
