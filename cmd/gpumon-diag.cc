@@ -467,6 +467,12 @@ int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, std::string
   }
   r.text("\n");
   *js += "}}";
+  // A floor only means something once links are involved: the 1-GPU row is a local copy.
+  const double floor_gbps = a.num("--min-busbw", 0);
+  if (floor_gbps > 0 && w > 1)
+    for (int i = 0; i < GMD_COLL_COUNT; i++)
+      if (peak[i] > 0 && peak[i] < floor_gbps)
+        r.fail("%s peaks at %.1f GB/s bus bandwidth on %d GPUs, under the %.1f GB/s floor", gmd_collective_name(i), peak[i], w, floor_gbps);
   return 0;
 }
 
@@ -567,7 +573,7 @@ void usage() {
           "  memtest [-g GPU] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N]\n"
           "  mfma    [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
           "  gemm    [-g GPU] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--min-tflops X] [--no-telemetry]\n"
-          "  rccl    [--gpus LIST] [--ops LIST] [--min-bytes N] [--max-bytes N] [--factor N] [--iters N] [--scaling] [--no-verify]\n"
+          "  rccl    [--gpus LIST] [--ops LIST] [--min-bytes N] [--max-bytes N] [--factor N] [--iters N] [--scaling] [--no-verify] [--min-busbw GBPS]\n"
           "  p2p     [--gpus LIST] [--bytes N] [--iters N]\n"
           "  run     -r 1|2|3 [-g GPU]\n");
 }

@@ -2,13 +2,15 @@
 //
 // Six STREAM-style kernels.  Every lane moves 16 bytes per access (one
 // global_load/store_dwordx4, 1 KiB per wave-instruction — the widest coalesced
-// access the memory pipeline has) and keeps kUnroll independent accesses in
-// flight; every workgroup walks its own contiguous span of the buffers (see
-// stream_kernel).  Buffers are sized far beyond the 256 MiB Infinity Cache by
-// the caller so the number reported is HBM3E, not L3.  Non-temporal accesses
-// keep the once-touched stream from displacing lines in L2 / Infinity Cache;
-// measured on MI355X (8 GiB buffers) they are worth +12 % on reads (7.2 TB/s),
-// +3-5 % on copies (5.5 TB/s) and cost 4-8 % on pure stores (6.1 TB/s plain).
+// access the memory pipeline has).  The kernels that store give every lane one
+// access and let the in-order dispatch of a very large grid do the traversal
+// (onepass_kernel); the read kernel walks one contiguous span per workgroup with
+// kUnroll independent loads in flight (stream_kernel).  Buffers are sized far
+// beyond the 256 MiB Infinity Cache by the caller so the number reported is
+// HBM3E, not L3.  Non-temporal accesses keep the once-touched stream from
+// displacing lines in L2 / Infinity Cache; measured on MI355X they are worth
+// +12 % on reads (7.2 TB/s), +4-8 % on copies and triads (6.7 / 6.6 TB/s) and
+// cost 2-4 % on pure stores (7.1 TB/s plain).
 #include "diag_common.h"
 
 namespace {
@@ -84,7 +86,47 @@ __global__ __launch_bounds__(kBlock) void stream_kernel(f32x4* __restrict__ a, f
   }
 }
 
-constexpr unsigned kMaxGrid = gmd::kCUs * 128;  // spans of >= 16 KiB; best measured point of the sweep
+// The kernels that store run as ONE access per lane and nothing else: workgroup w
+// touches elements [w*BS, (w+1)*BS) and exits.  The dispatcher hands workgroups out
+// in order, so the addresses in flight form one compact window that slides through
+// the buffers, and reads and writes of the same few DRAM pages arrive together.
+// Measured on MI355X (4 GiB buffers, TB/s; scripts/stream_sweep.hip):
+//   copy   5.5 (128 KiB spans) -> 6.5 (256 lanes) -> 6.7 (64 lanes), non-temporal
+//   triad  5.6                 -> 6.4             -> 6.6
+//   write  6.05                -> 6.85 (256 lanes) -> 7.1 with 4 workgroups per CU
+// A pure store stream is dispatch-bound with 64-lane workgroups (4.8) and likes fewer
+// waves in flight: 40 KiB of (unused) dynamic LDS caps it at 4 workgroups per CU.
+template <int OP, bool NT, int BS>
+__global__ __launch_bounds__(BS) void onepass_kernel(f32x4* __restrict__ a, f32x4* __restrict__ b, f32x4* __restrict__ c,
+                                                     float s, uint64_t n4) {
+  const uint64_t i = (uint64_t)blockIdx.x * BS + threadIdx.x;
+  if (i >= n4) return;
+  if constexpr (OP == GMD_STREAM_COPY) st<NT>(c + i, ld<NT>(a + i));
+  if constexpr (OP == GMD_STREAM_SCALE) st<NT>(b + i, s * ld<NT>(c + i));
+  if constexpr (OP == GMD_STREAM_ADD) st<NT>(c + i, ld<NT>(a + i) + ld<NT>(b + i));
+  if constexpr (OP == GMD_STREAM_TRIAD) st<NT>(a + i, ld<NT>(b + i) + s * ld<NT>(c + i));
+  if constexpr (OP == GMD_STREAM_WRITE) st<NT>(a + i, f32x4{s, s, s, s});
+}
+constexpr int kMoveBlock = 64;            // copy / scale / add / triad
+constexpr int kStoreBlock = 256;          // write
+constexpr int kStoreLdsBytes = 40 * 1024; // 160 KiB / 40 KiB = 4 workgroups (16 waves) per CU
+
+template <int OP, bool NT>
+unsigned launch_onepass(f32x4* a, f32x4* b, f32x4* c, float s, uint64_t n4, hipStream_t st) {
+  constexpr int BS = OP == GMD_STREAM_WRITE ? kStoreBlock : kMoveBlock;
+  // A launch holds fewer than 2^32 work-items: 32 GiB of 16-byte elements per launch.
+  constexpr uint64_t kPerLaunch = 1ull << 31;
+  unsigned grid = 0;
+  for (uint64_t off = 0; off < n4; off += kPerLaunch) {
+    const uint64_t n = std::min(kPerLaunch, n4 - off);
+    grid = (unsigned)((n + BS - 1) / BS);
+    onepass_kernel<OP, NT, BS><<<grid, BS, OP == GMD_STREAM_WRITE ? kStoreLdsBytes : 0, st>>>(
+        a ? a + off : a, b ? b + off : b, c ? c + off : c, s, n);
+  }
+  return grid;
+}
+
+constexpr unsigned kMaxGrid = gmd::kCUs * 128;  // READ: spans of >= 16 KiB; best measured point of the sweep
 static_assert(kMaxGrid <= GMD_STREAM_SINK_FLOATS, "a caller-provided READ sink must cover the grid");
 
 // Grid and span (in 16-byte elements, a multiple of one unrolled workgroup pass).
@@ -103,16 +145,18 @@ __global__ void init_kernel(f32x4* a, f32x4* b, f32x4* c, uint64_t n4) {
 
 template <bool NT>
 unsigned launch(int kernel, f32x4* a, f32x4* b, f32x4* c, float s, uint64_t n4, float* sink, hipStream_t st) {
-  unsigned grid;
+  unsigned grid = 0;
   uint64_t span;
-  plan(n4, &grid, &span);
   switch (kernel) {
-    case GMD_STREAM_COPY: stream_kernel<GMD_STREAM_COPY, NT><<<grid, kBlock, 0, st>>>(a, b, c, s, n4, span, sink); break;
-    case GMD_STREAM_SCALE: stream_kernel<GMD_STREAM_SCALE, NT><<<grid, kBlock, 0, st>>>(a, b, c, s, n4, span, sink); break;
-    case GMD_STREAM_ADD: stream_kernel<GMD_STREAM_ADD, NT><<<grid, kBlock, 0, st>>>(a, b, c, s, n4, span, sink); break;
-    case GMD_STREAM_TRIAD: stream_kernel<GMD_STREAM_TRIAD, NT><<<grid, kBlock, 0, st>>>(a, b, c, s, n4, span, sink); break;
-    case GMD_STREAM_READ: stream_kernel<GMD_STREAM_READ, NT><<<grid, kBlock, 0, st>>>(a, b, c, s, n4, span, sink); break;
-    case GMD_STREAM_WRITE: stream_kernel<GMD_STREAM_WRITE, NT><<<grid, kBlock, 0, st>>>(a, b, c, s, n4, span, sink); break;
+    case GMD_STREAM_COPY: return launch_onepass<GMD_STREAM_COPY, NT>(a, b, c, s, n4, st);
+    case GMD_STREAM_SCALE: return launch_onepass<GMD_STREAM_SCALE, NT>(a, b, c, s, n4, st);
+    case GMD_STREAM_ADD: return launch_onepass<GMD_STREAM_ADD, NT>(a, b, c, s, n4, st);
+    case GMD_STREAM_TRIAD: return launch_onepass<GMD_STREAM_TRIAD, NT>(a, b, c, s, n4, st);
+    case GMD_STREAM_WRITE: return launch_onepass<GMD_STREAM_WRITE, NT>(a, b, c, s, n4, st);
+    case GMD_STREAM_READ:  // one partial sum per workgroup: spans, so that the sink stays small
+      plan(n4, &grid, &span);
+      stream_kernel<GMD_STREAM_READ, NT><<<grid, kBlock, 0, st>>>(a, b, c, s, n4, span, sink);
+      break;
   }
   return grid;
 }

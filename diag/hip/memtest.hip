@@ -5,9 +5,10 @@
 // test covers twice the memory a copy-compare test could.  Patterns follow the
 // classic memory-test repertoire (walking ones / zeros, address-in-address,
 // checkerboard and its inverse, a counter-based pseudo-random fill, modulo-20).
-// Both passes move 16 bytes per lane per access (two 64-bit words); every
-// workgroup walks its own contiguous span (128 workgroups per CU) and the
-// pattern is a template parameter, so the inner loop is loads / stores plus a few
+// Both passes move 16 bytes per lane per access (two 64-bit words).  The write
+// pass is one store per lane over a very large grid (see fill_kernel); in the read
+// pass every workgroup walks its own contiguous span (128 workgroups per CU).  The
+// pattern is a template parameter, so the kernels are loads / stores plus a few
 // integer ops.  Mismatches are counted with one atomic per mismatching lane
 // (rare) and the first few are logged with offset, expected and actual value so
 // a failing HBM stack / channel can be located.
@@ -50,25 +51,20 @@ constexpr unsigned kMaxGrid = gmd::kCUs * 128;
 
 // PAT is a compile-time constant so the pattern switch folds away; every workgroup
 // walks its own contiguous span (see gmd::span_plan).
+// The write pass gives every lane ONE 16-byte store: workgroup w fills elements
+// [256 w, 256 w + 256) and exits, and the in-order dispatch of the (very large)
+// grid does the traversal, so the stores in flight cover one compact window that
+// slides through the chunk.  Measured against 128 KiB spans per workgroup this is
+// 6.0 -> 6.85 TB/s, and 7.1 TB/s with 4 workgroups per CU instead of 8 (kFillLdsBytes
+// of unused dynamic LDS is the occupancy cap).  Plain stores: a pure store stream
+// is faster without the non-temporal hint.
+constexpr int kFillLdsBytes = 40 * 1024;
 template <uint32_t PAT>
-__global__ __launch_bounds__(kBlock) void fill_kernel(u64x2* __restrict__ buf, uint64_t n2, uint64_t span,
-                                                      uint64_t base_word, uint64_t seed) {
-  uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x;
-  const uint64_t end = min((uint64_t)(blockIdx.x + 1) * span, n2);
-  for (; i + (kUnroll - 1) * kBlock < end; i += kUnroll * kBlock) {
-    u64x2 v[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      const uint64_t w = base_word + 2 * (i + u * kBlock);
-      v[u] = u64x2{expected_word(PAT, w, seed), expected_word(PAT, w + 1, seed)};
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) buf[i + u * kBlock] = v[u];  // plain stores: a pure-store stream is faster without nt
-  }
-  for (; i < end; i += kBlock) {
-    const uint64_t w = base_word + 2 * i;
-    buf[i] = u64x2{expected_word(PAT, w, seed), expected_word(PAT, w + 1, seed)};
-  }
+__global__ __launch_bounds__(kBlock) void fill_kernel(u64x2* __restrict__ buf, uint64_t n2, uint64_t base_word, uint64_t seed) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n2) return;
+  const uint64_t w = base_word + 2 * i;
+  buf[i] = u64x2{expected_word(PAT, w, seed), expected_word(PAT, w + 1, seed)};
 }
 
 struct VerifyOut {
@@ -138,12 +134,15 @@ __global__ __launch_bounds__(kBlock) void verify_kernel(const u64x2* __restrict_
   }
 
 void launch_fill(u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t pattern, uint64_t seed, hipStream_t st) {
-  unsigned grid;
-  uint64_t span;
-  gmd::span_plan(n2, (uint64_t)kBlock * kUnroll, kMaxGrid, &grid, &span);
-#define CALL(P) fill_kernel<P><<<grid, kBlock, 0, st>>>(buf, n2, span, base_word, seed)
-  GMD_FOR_PATTERN(pattern, CALL)
+  // A launch holds fewer than 2^32 work-items: 32 GiB per launch.
+  constexpr uint64_t kPerLaunch = 1ull << 31;
+  for (uint64_t off = 0; off < n2; off += kPerLaunch) {
+    const uint64_t n = std::min(kPerLaunch, n2 - off);
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+#define CALL(P) fill_kernel<P><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed)
+    GMD_FOR_PATTERN(pattern, CALL)
 #undef CALL
+  }
 }
 
 void launch_verify(const u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t pattern, uint64_t seed, VerifyOut* out,

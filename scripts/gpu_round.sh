@@ -35,6 +35,12 @@ for s in $STEPS; do
       step diag_rccl 300 build/bin/gpumon-diag rccl --max-bytes 256M --factor 16
       ;;
     gemmcheck) step gemm_check 600 python -u scripts/gpu_gemm_check.py ;;
+    scrape)
+      # exporter cost at 1 s resolution: real device library, then the same binary while the GPU soaks
+      step scrape_amdsmi 120 python -u scripts/scrape_bench.py --backend amdsmi --seconds 30 --out "$OUT/scrape_amdsmi.json"
+      ;;
+    probe) step probe 300 python -u scripts/gpu_probe.py ;;
+    copyref) step copy_ref 300 python -u scripts/gpu_copy_ref.py ;;
     prof)
       # kernel trace of a short bench run; rocprofv3 wants a writable cwd-independent TMPDIR
       export TMPDIR=/tmp
