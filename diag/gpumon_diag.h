@@ -159,6 +159,11 @@ GMD_API int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, in
  * Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
 
+/* Timing-only ablation builds (make diag-ablate): per-workgroup pairs (shader-clock ticks,
+ * 100 MHz real-time ticks) of the last launch of a stamped variant.  GMD_ERR_UNSUPPORTED in
+ * the product library. */
+GMD_API int gmd_gemm_read_stamps(unsigned long long* out, int n_pairs);
+
 /* ---------------------------------------------------------- interconnect -- */
 /* Single-process RCCL sweep: one communicator per listed GPU (ncclCommInitAll),
  * collectives issued as one group per iteration.  librccl is loaded at run time.

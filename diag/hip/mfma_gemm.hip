@@ -273,8 +273,16 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_barrier();            \
   __builtin_amdgcn_sched_barrier(0)
 
+#ifdef GMD_GEMM_ABLATE
+// Clock stamps of the ablation builds: per workgroup, shader-clock ticks and 100 MHz
+// real-time ticks spent in the kernel (ABL bit 4).  Nothing else reads this buffer.
+constexpr int kStampSlots = 4096;
+__device__ unsigned long long g_gemm_stamps[2 * kStampSlots];
+#endif
+
 // ABL is for timing-only ablation builds (make diag-ablate; results are wrong by design):
-// bit 0 drops the fragment reads of the loop, bit 1 the LDS-DMA and its waits, bit 2 the MFMAs.
+// bit 0 drops the fragment reads of the loop, bit 1 the LDS-DMA and its waits, bit 2 the MFMAs;
+// bit 3 points every workgroup at the operands of tile (0, 0) (an always-L2-resident stream).
 template <int DT, int ABL = 0, int AHEAD = kAheadDefault>
 __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
@@ -289,8 +297,16 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
   const int wgid = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (blockIdx.x >> 3);
   int tm, tn;
   tile_of(wgid, M / BM, N / BN, &tm, &tn);
-  const char* gA = A + (size_t)tm * BM * row_bytes;
-  const char* gB = B + (size_t)tn * BN * row_bytes;
+#ifdef GMD_GEMM_ABLATE
+  unsigned long long stamp_t0 = 0, stamp_r0 = 0;
+  if constexpr (ABL & 16) {
+    stamp_t0 = __builtin_amdgcn_s_memtime();
+    stamp_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  // ABL bit 3: every workgroup streams the operands of tile (0, 0), so all but the first fetch of a line hit L2.
+  const char* gA = A + (size_t)((ABL & 8) ? 0 : tm) * BM * row_bytes;
+  const char* gB = B + (size_t)((ABL & 8) ? 0 : tn) * BN * row_bytes;
 
   // Staging: this wave fills pieces 2*wave and 2*wave+1 (8 rows x 128 B each) of every slot.
   // Slot-local row l maps to tile row (l>>6)*128 + (l&63) [+64 for hi] in A and (l>>5)*64 + (l&31) [+32 for hi] in B.
@@ -443,6 +459,16 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
     phase(std::integral_constant<int, 7>{}, T{}, kt0);
   }
   if (wr == 0) { GMD_PHASE_FENCE(); }  // the barrier the second wave row took up front
+#ifdef GMD_GEMM_ABLATE
+  if constexpr (ABL & 16) {
+    asm volatile("s_nop 0" ::"v"(acc[7][3]));  // stamp behind the last MFMA's result
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && wgid < kStampSlots) {
+      g_gemm_stamps[2 * wgid] = t1 - stamp_t0;
+      g_gemm_stamps[2 * wgid + 1] = r1 - stamp_r0;
+    }
+  }
+#endif
 
   const int m0 = tm * BM + wr * 128 + fr;
   const int n0 = tn * BN + wc * 64 + fq * 4;
@@ -646,6 +672,19 @@ int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t ro
     GMD_HIP(hipGetLastError());                                                                                        \
     return GMD_OK;                                                                                                     \
   }
+#define GMD_MIX_CASE(ID, MASK, D)                                                                                      \
+  case ID: {                                                                                                           \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, MASK, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  kLdsBytes));                                                                         \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    gemm_pp_kernel<DT, MASK, D><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n,   \
+                                                                    row_bytes);                                        \
+    GMD_HIP(hipGetLastError());                                                                                        \
+    return GMD_OK;                                                                                                     \
+  }
   switch (gemm_variant()) {
     GMD_AHEAD_CASE(5)
     GMD_AHEAD_CASE(6)
@@ -657,6 +696,17 @@ int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t ro
     GMD_ABL_CASE(5)
     GMD_ABL_CASE(6)
     GMD_ABL_CASE(7)
+    GMD_ABL_CASE(8)   // 18: full pipeline, operands always L2-resident
+    GMD_ABL_CASE(13)  // 23: DMA only, operands always L2-resident
+    GMD_MIX_CASE(33, 5, 5)  // DMA only at issue distance 5
+    GMD_MIX_CASE(34, 5, 6)  // DMA only at issue distance 6
+    // 41..46: the same arms with clock stamps (read back with gmd_gemm_read_stamps)
+    GMD_MIX_CASE(41, 16, kAheadDefault)
+    GMD_MIX_CASE(42, 16 | 3, kAheadDefault)
+    GMD_MIX_CASE(43, 16 | 1, kAheadDefault)
+    GMD_MIX_CASE(44, 16 | 2, kAheadDefault)
+    GMD_MIX_CASE(45, 16 | 5, kAheadDefault)
+    GMD_MIX_CASE(46, 16 | 8, kAheadDefault)
     default: break;
   }
 #endif
@@ -674,7 +724,8 @@ extern "C" {
 
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
-  if ((variant >= 11 && variant <= 17) || (variant >= 25 && variant <= 27)) {
+  if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
+      (variant >= 41 && variant <= 46)) {
     g_gemm_variant = variant;
     return GMD_OK;
   }
@@ -682,6 +733,19 @@ int gmd_gemm_set_variant(int variant) {
   if (variant < 0 || variant > 1) return GMD_ERR_BADPARAM;
   g_gemm_variant = variant;
   return GMD_OK;
+}
+
+// Ablation builds only: per-workgroup (shader ticks, 100 MHz ticks) pairs of the last stamped launch.
+int gmd_gemm_read_stamps(unsigned long long* out, int n_pairs) {
+#ifdef GMD_GEMM_ABLATE
+  if (!out || n_pairs <= 0 || n_pairs > kStampSlots) return GMD_ERR_BADPARAM;
+  GMD_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 2 * n_pairs));
+  return GMD_OK;
+#else
+  (void)out;
+  (void)n_pairs;
+  return GMD_ERR_UNSUPPORTED;
+#endif
 }
 
 int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream) {

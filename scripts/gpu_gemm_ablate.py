@@ -18,7 +18,10 @@ from k8s_gpu_monitor_amd.ops import diag  # noqa: E402
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 NAMES = {1: "full", 25: "ahead 5", 26: "ahead 6", 27: "ahead 7", 11: "no reads", 12: "no dma", 13: "no reads, no dma", 14: "no mfma", 15: "no reads, no mfma",
-         16: "no dma, no mfma", 17: "barriers only", 0: "simple loop"}
+         16: "no dma, no mfma", 17: "barriers only", 0: "simple loop",
+         18: "full, operands L2-resident", 23: "dma only, operands L2-resident", 33: "dma only, ahead 5", 34: "dma only, ahead 6"}
+if os.environ.get("GEMM_ABLATE_ONLY"):
+    NAMES = {v: NAMES[v] for v in [1] + [int(x) for x in os.environ["GEMM_ABLATE_ONLY"].split(",")]}
 out = []
 # the issue-distance variants must compute the same bits as the simple loop, launch after launch
 for dtype in ("bf16", "mxfp8"):
