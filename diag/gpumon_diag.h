@@ -154,8 +154,10 @@ GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double s
  * bf16: A,B bf16, C bf16.  fp8: A,B OCP e4m3, C bf16.  M,N multiples of 256; K multiple of 64 (bf16) / 128 (fp8). */
 GMD_API int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream);
 
-/* GEMM schedule: 1 = phase-interleaved pipeline (default; needs an even number of
- * 128-byte K-tiles, otherwise the launch falls back), 0 = simple double-buffered loop.
+/* GEMM schedule: -1 = the faster pipeline for the dtype (default: eight waves for bf16, four
+ * for MX-fp8), 1 = eight waves x 128x64 phase-interleaved, 2 = four waves x 128x128 with the
+ * accumulators in AGPRs (both need an even number of 128-byte K-tiles, otherwise the launch
+ * falls back), 0 = simple double-buffered loop.  All three give bit-identical results.
  * Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
 

@@ -481,6 +481,220 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
     }
 }
 
+// ---- (2c) four waves, 128 x 128 of C each ---------------------------------------
+//
+// In cycles the eight-wave pipeline above is within 2 % of its MFMAs alone; what it
+// loses is clock: the chip is at its power cap and holds ~1.73 GHz under it against
+// ~2.38 GHz for the MFMAs alone, and the LDS fragment reads are the largest draw
+// (scripts/gpu_gemm_clock.py).  A wave that owns 128 x 128 of C instead of 128 x 64
+// reads (128 + 128) rows per K-tile for twice the MFMAs: a third fewer LDS bytes per
+// FLOP.  That takes 256 accumulator registers, so one wave per SIMD, four per
+// workgroup, and no partner wave to hide behind: every phase interleaves its own
+// memory operations between its own MFMAs.
+//
+// * Same LDS image, swizzle and 8-slot ring of 16 KiB half-tiles as above, in the
+//   order A-lo, B-lo, B-hi, A-hi per K-tile ("lo"/"hi": the first / second 64 rows
+//   of each wave's 128).  Four phases per K-tile, one 64 x 64 quadrant each:
+//   (lo,lo) (lo,hi) (hi,hi) (hi,lo), 32 MFMAs (16 for MX-fp8) = 512 matrix cycles.
+// * Phase g computes on fragments already in registers, and between its first
+//   twelve MFMAs issues the 8 ds_read_b128 of half-tile g+2 (into the fragment set
+//   that is idle: two A sets, two B sets that swap roles with K-tile parity) and the
+//   4 LDS-DMA instructions of half-tile g+8.  Every second phase ends with
+//   vmcnt(16) (half-tiles up to g+4 landed, four still in flight), lgkmcnt(0) and
+//   a barrier; the phases in between end with nothing.
+// * Slot (g+8) % 8 was last read in phase g-2, at least one barrier earlier.
+// * Measured (8192^3, one device, interleaved): fewer LDS bytes buy +2-5 % clock at
+//   +4-6 % cycles (exposed barriers and issue gaps).  Net: 2 % behind the eight-wave
+//   kernel on bf16, 1.5-2.5 % ahead on MX-fp8.
+constexpr int kThreadsW4 = 256;
+constexpr int kAheadW4 = 8;
+
+// The 64 accumulators fill the 256 AGPRs exactly and must be updated in place.  Written
+// with the builtin, hipcc (ROCm 7.2) spreads them over VGPRs and AGPRs and moves them
+// about with ~2 v_accvgpr copies per MFMA; the "+a" constraint pins each one to its
+// AGPR quad.  An MFMA whose C operand is the previous MFMA's whole result needs no wait
+// states; the epilogue's reads come after W4_DRAIN.  `unit` holds 0x7f7f7f7f: E8M0
+// scale 2^0 for all four blocks of both operands.
+template <int DT>
+__device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x8& b, int ks, int unit) {
+  if constexpr (DT == GMD_DT_BF16) {
+    const i32x4 bh = ks ? __builtin_shufflevector(b, b, 4, 5, 6, 7) : __builtin_shufflevector(b, b, 0, 1, 2, 3);
+    const i32x4 ah = ks ? __builtin_shufflevector(a, a, 4, 5, 6, 7) : __builtin_shufflevector(a, a, 0, 1, 2, 3);
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(bh), "v"(ah));
+  } else {
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc) : "v"(b), "v"(a), "v"(unit));
+  }
+}
+#define W4_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+
+template <int DT, int ABL = 0>  // ABL 16: clock stamps (ablation builds only)
+__global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restrict__ A, const char* __restrict__ B,
+                                                             __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+#ifdef GMD_GEMM_ABLATE
+  unsigned long long stamp_t0 = 0, stamp_r0 = 0;
+  if constexpr (ABL & 16) {
+    stamp_t0 = __builtin_amdgcn_s_memtime();
+    stamp_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8n = nwg & 7;
+  const int wgid = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (blockIdx.x >> 3);
+  int tm, tn;
+  tile_of(wgid, M / BM, N / BN, &tm, &tn);
+  const char* gA = A + (size_t)tm * BM * row_bytes;
+  const char* gB = B + (size_t)tn * BN * row_bytes;
+
+  // Staging: this wave fills pieces 4*wave .. 4*wave+3 (8 rows x 128 B each) of every slot.  Slot-local row l is
+  // tile row (l>>6)*128 + (l&63) [+64 for hi], for A and B alike.
+  const int r8 = lane >> 3;
+  const uint32_t src_chunk = (uint32_t)(((lane & 7) ^ chunk_swizzle<DT>(r8)) * 16);
+  uint32_t off[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int l = (4 * wave + i) * 8 + r8;
+    off[i] = (uint32_t)(((l >> 6) * 128 + (l & 63)) * row_bytes) + src_chunk;
+  }
+  const size_t hi_off = 64 * row_bytes;
+  char* const my_pieces = smem + wave * 4096;
+
+  // kind: 0 A-lo, 1 B-lo, 2 B-hi, 3 A-hi.  Wave-uniform part of the source address of one half-tile, kept in SGPRs.
+  auto piece_base = [&](int kind, int kt) {
+    const char* base = ((kind == 0 || kind == 3) ? gA : gB) + ((kind >= 2) ? hi_off : 0) + (size_t)kt * BKB;
+    asm volatile("" : "+s"(base));
+    return base;
+  };
+  auto dma = [&](const char* base, int slot, int i) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
+                                     (__attribute__((address_space(3))) void*)(my_pieces + slot * kHalfBytes + i * 1024), 16, 0, 0);
+  };
+
+  // Fragment read offsets inside a slot (local rows: A wr*64 + fr, B wc*64 + fr).
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    const int ch = DT == GMD_DT_BF16 ? ks * 4 + fq : 2 * fq + ks;
+    a_off[ks] = lds_off<DT>(wr * 64 + fr, ch);
+    b_off[ks] = lds_off<DT>(wc * 64 + fr, ch);
+  }
+  // One of the eight 16-byte reads of a half-tile's fragments: block j>>1 (16 rows), half j&1.
+  auto read_one = [&](i32x8 (&f)[4], int slot, bool is_a, int j) {
+    const i32x4 v = *(const i32x4*)(smem + slot * kHalfBytes + (is_a ? a_off[j & 1] : b_off[j & 1]) + (j >> 1) * 2048);
+    if (j & 1) f[j >> 1].hi = v;
+    else f[j >> 1].lo = v;
+  };
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x8 aL[4], aH[4], bX[4], bY[4];
+  int unit;
+  asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(unit));
+
+  // Prologue: half-tiles 0..7 (K-tiles 0 and 1) in flight, 0..3 landed (phases 0 and 1 read 2 and 3), 0 and 1 in registers.
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const char* base = piece_base(j & 3, j >> 2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) dma(base, j, i);
+  }
+  wait_vmcnt<4 * (kAheadW4 - 4)>();
+  GMD_PHASE_FENCE();
+#pragma unroll
+  for (int j = 0; j < 8; j++) read_one(aL, 0, true, j);
+#pragma unroll
+  for (int j = 0; j < 8; j++) read_one(bX, 1, false, j);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  GMD_PHASE_FENCE();
+
+  // One phase.  P: phase within a pair of K-tiles (0..7).  There is ONE loop body and no specialised last
+  // iteration: hipcc allocates a separate tail separately and bridges the two with v_accvgpr copies placed
+  // right against the asm MFMAs, whose wait states it cannot see (measured: wrong sums).  The last pair
+  // therefore keeps issuing (the last K-tile again, into slots nobody reads any more) and keeps reading
+  // (fragments nobody multiplies), which also keeps every vmcnt immediate the same.
+  const int last_kt = (int)(row_bytes / BKB) - 1;
+  auto phase = [&](auto PH, int kt0) {
+    constexpr int P = decltype(PH)::value;
+    constexpr int par = P >> 2, p = P & 3;
+    constexpr int MB0 = (p >= 2) ? 4 : 0, NB0 = (p == 1 || p == 2) ? 4 : 0;
+    i32x8(&Af)[4] = (p < 2) ? aL : aH;
+    i32x8(&Bf)[4] = (p == 0 || p == 3) ? (par ? bY : bX) : (par ? bX : bY);  // B-lo sits in bX on even K-tiles, bY on odd
+    // read during this phase: half-tile P+2 of the pair
+    constexpr int R = P + 2, rk = R & 3, rpar = (R >> 2) & 1;
+    i32x8(&Rf)[4] = rk == 0 ? aL : rk == 3 ? aH : (rk == 1) == (rpar == 0) ? bX : bY;
+    constexpr int rslot = R & 7;
+    // issued during this phase: half-tile P+8, into the slot half-tile P leaves
+    const char* base = piece_base(p, min(kt0 + 2 + par, last_kt));
+    constexpr int NM = DT == GMD_DT_BF16 ? 32 : 16;
+#pragma unroll
+    for (int i = 0; i < NM; i++) {
+      const int ks = DT == GMD_DT_BF16 ? i >> 4 : 0, mb = (i >> 2) & 3, nb = i & 3;
+      mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], ks, unit);
+      if (i < 8) read_one(Rf, rslot, rk == 0 || rk == 3, i);
+      else if (i < 12) dma(base, P, i - 8);
+      if (i < 12) __builtin_amdgcn_sched_barrier(0);
+    }
+    // Keep both operand sets whole until the phase's last MFMA, so that no half of them is handed to one of
+    // this phase's ds_reads or address computations while MFMAs that read it are still to issue.
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("" ::"v"(Af[j]), "v"(Bf[j]));
+    // With one wave per SIMD every barrier is exposed matrix-pipe time (~45 cycles), so there is one per TWO
+    // phases: after odd phase h, half-tiles up to h+4 have landed (h+1 and h+2 read h+3 and h+4) and the reads
+    // of phases h-1 and h are done, which frees the slots that phases h+1 and h+2 refill.
+    if constexpr (P & 1) {
+      wait_vmcnt<4 * (kAheadW4 - 4)>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      GMD_PHASE_FENCE();
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int npairs = (int)(row_bytes / BKB) >> 1;
+  for (int it = 0; it < npairs; it++) {
+    const int kt0 = 2 * it;
+    phase(std::integral_constant<int, 0>{}, kt0);
+    phase(std::integral_constant<int, 1>{}, kt0);
+    phase(std::integral_constant<int, 2>{}, kt0);
+    phase(std::integral_constant<int, 3>{}, kt0);
+    phase(std::integral_constant<int, 4>{}, kt0);
+    phase(std::integral_constant<int, 5>{}, kt0);
+    phase(std::integral_constant<int, 6>{}, kt0);
+    phase(std::integral_constant<int, 7>{}, kt0);
+  }
+  wait_vmcnt<0>();  // the last pair's surplus DMA must not outlive the workgroup's LDS
+  __builtin_amdgcn_sched_barrier(0);
+  W4_DRAIN();
+  __builtin_amdgcn_sched_barrier(0);
+#ifdef GMD_GEMM_ABLATE
+  if constexpr (ABL & 16) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && wgid < kStampSlots) {
+      g_gemm_stamps[2 * wgid] = t1 - stamp_t0;
+      g_gemm_stamps[2 * wgid + 1] = r1 - stamp_r0;
+    }
+  }
+#endif
+
+  const int m0 = tm * BM + wr * 128 + fr;
+  const int n0 = tn * BN + wc * 128 + fq * 4;
+#pragma unroll
+  for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+    for (int nb = 0; nb < 8; nb++) {
+      bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
+      *(bf16x4*)(C + (size_t)(m0 + mb * 16) * N + n0 + nb * 16) = o;
+    }
+}
+
 // ---- output checksum (integer, order-independent -> bitwise reproducible) ----
 __global__ void checksum_kernel(const uint4* __restrict__ c, uint64_t n16, unsigned long long* out) {
   unsigned long long s = 0;
@@ -622,14 +836,16 @@ double peak_flops_per_mfma(int dt) {
   }
 }
 
-// Which GEMM schedule runs: 1 = phase-interleaved pipeline (default), 0 = the simple
-// double-buffered loop (kept as the A/B baseline and for odd K-tile counts).
-int g_gemm_variant = -1;
+// Which GEMM schedule runs: -1 = the faster pipeline for the dtype (default), 2 = four waves of
+// 128 x 128, 1 = eight waves of 128 x 64, 0 = the simple double-buffered loop (kept as the A/B
+// baseline and for odd K-tile counts).
+constexpr int kVariantUnset = -2;
+int g_gemm_variant = kVariantUnset;
 
 int gemm_variant() {
-  if (g_gemm_variant < 0) {
+  if (g_gemm_variant == kVariantUnset) {
     const char* e = getenv("GMD_GEMM_VARIANT");
-    g_gemm_variant = e && *e ? atoi(e) : 1;
+    g_gemm_variant = e && *e ? atoi(e) : -1;
   }
   return g_gemm_variant;
 }
@@ -707,10 +923,29 @@ int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t ro
     GMD_MIX_CASE(44, 16 | 2, kAheadDefault)
     GMD_MIX_CASE(45, 16 | 5, kAheadDefault)
     GMD_MIX_CASE(46, 16 | 8, kAheadDefault)
+    case 51: {  // the four-wave kernel with clock stamps
+      static bool once = false;
+      if (!once) {
+        GMD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<DT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        once = true;
+      }
+      gemm_w4_kernel<DT, 16><<<grid, kThreadsW4, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+      GMD_HIP(hipGetLastError());
+      return GMD_OK;
+    }
     default: break;
   }
 #endif
-  if (gemm_variant() == 1 && ktiles >= 2 && (ktiles & 1) == 0)
+  // auto: the four-wave kernel is the faster one for MX-fp8 (+1.5-2.5 %), the eight-wave one for bf16 (+2 %)
+  const int variant = gemm_variant() < 0 ? (DT == GMD_DT_BF16 ? 1 : 2) : gemm_variant();
+  if (variant == 2 && ktiles >= 2 && (ktiles & 1) == 0) {
+    static bool w4_attr = false;
+    if (!w4_attr) {
+      GMD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+      w4_attr = true;
+    }
+    gemm_w4_kernel<DT><<<grid, kThreadsW4, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+  } else if (variant >= 1 && ktiles >= 2 && (ktiles & 1) == 0)
     gemm_pp_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
   else
     gemm_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
@@ -725,12 +960,12 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46)) {
+      (variant >= 41 && variant <= 46) || variant == 51) {
     g_gemm_variant = variant;
     return GMD_OK;
   }
 #endif
-  if (variant < 0 || variant > 1) return GMD_ERR_BADPARAM;
+  if (variant < -1 || variant > 2) return GMD_ERR_BADPARAM;
   g_gemm_variant = variant;
   return GMD_OK;
 }

@@ -1,5 +1,5 @@
-"""A/B of the two GEMM schedules on random data: numerics against fp32 matmul, then
-interleaved timing (variant 0 / 1 alternate inside one process) at several shapes,
+"""A/B of the three GEMM schedules on random data: numerics against fp32 matmul, then
+interleaved timing (variants 0 / 1 / 2 alternate inside one process) at several shapes,
 next to torch.matmul (hipBLASLt) for bf16.  Writes gpurun_out/gemm_ab.json."""
 import json
 import os
@@ -31,7 +31,7 @@ for dtype in ("bf16", "mxfp8"):
         a, b = inputs(m, n, k, dtype, seed=m + n + k)
         ref = a.float() @ b.float().t()
         res = {}
-        for v in (0, 1):
+        for v in (0, 1, 2):
             diag.gemm_set_variant(v)
             c = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=dev)
             for _ in range(3):  # repeated: a race would show as run-to-run differences
@@ -42,13 +42,13 @@ for dtype in ("bf16", "mxfp8"):
             ok = bool(torch.isfinite(c.float()).all()) and err < 6e-3
             ok_all &= ok
             out["numerics"].append({"dtype": dtype, "shape": [m, n, k], "variant": v, "rel_err": err, "ok": ok})
-        same = bool(torch.equal(res[0], res[1]))
+        same = bool(torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]))
         out["numerics"].append({"dtype": dtype, "shape": [m, n, k], "variants_bit_identical": same})
-        print(dtype, (m, n, k), "err", [round(x["rel_err"], 5) for x in out["numerics"][-3:-1]], "identical", same, flush=True)
+        print(dtype, (m, n, k), "err", [round(x["rel_err"], 5) for x in out["numerics"][-4:-1]], "identical", same, flush=True)
 
 # race screen: many launches of the pipeline variant must give one bit pattern
-diag.gemm_set_variant(1)
-for dtype in ("bf16", "mxfp8"):
+for rv, dtype in [(v, d) for v in (1, 2) for d in ("bf16", "mxfp8")]:
+    diag.gemm_set_variant(rv)
     a, b = inputs(4096, 4096, 4096, dtype, seed=5)
     c = torch.empty(4096, 4096, dtype=torch.bfloat16, device=dev)
     diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), 4096, 4096, 4096, stream)
@@ -62,9 +62,9 @@ for dtype in ("bf16", "mxfp8"):
             bad += int(not torch.equal(c, first))
     ref = a.float() @ b.float().t()
     err = ((first.float() - ref).abs().max() / ref.abs().max()).item()
-    out["numerics"].append({"dtype": dtype, "race_screen_mismatches": bad, "rel_err_4096": err})
+    out["numerics"].append({"dtype": dtype, "variant": rv, "race_screen_mismatches": bad, "rel_err_4096": err})
     ok_all &= bad == 0 and err < 6e-3
-    print(dtype, "race screen mismatches", bad, "err", err, flush=True)
+    print(dtype, "variant", rv, "race screen mismatches", bad, "err", err, flush=True)
 
 
 def timeit(fn, n):
@@ -84,10 +84,10 @@ for dtype in ("bf16", "mxfp8"):
         a, b = inputs(s, s, s, dtype, seed=s)
         c = torch.empty(s, s, dtype=torch.bfloat16, device=dev)
         flops = 2.0 * s ** 3
-        best = {0: 1e9, 1: 1e9, "torch": 1e9}
+        best = {0: 1e9, 1: 1e9, 2: 1e9, "torch": 1e9}
         n = 20 if s <= 8192 else 5
         for rep in range(4):  # interleaved A/B
-            for v in (0, 1):
+            for v in (0, 1, 2):
                 diag.gemm_set_variant(v)
                 ms = timeit(lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), s, s, s, stream), n)
                 best[v] = min(best[v], ms)
@@ -95,7 +95,7 @@ for dtype in ("bf16", "mxfp8"):
                 bt = b.t()
                 ms = timeit(lambda: torch.matmul(a, bt), n)
                 best["torch"] = min(best["torch"], ms)
-        row = {"dtype": dtype, "size": s, "tflops_v0": flops / best[0] / 1e9, "tflops_v1": flops / best[1] / 1e9}
+        row = {"dtype": dtype, "size": s, "tflops_v0": flops / best[0] / 1e9, "tflops_v1": flops / best[1] / 1e9, "tflops_v2": flops / best[2] / 1e9}
         if dtype == "bf16":
             row["tflops_torch"] = flops / best["torch"] / 1e9
         out["timing"].append(row)

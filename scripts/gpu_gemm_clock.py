@@ -23,7 +23,10 @@ lib.gmd_gemm_read_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 SOAK_S = float(os.environ.get("SOAK_S", "2.0"))
-ARMS = {41: "full", 42: "mfma + barriers", 43: "no reads", 44: "no dma", 45: "dma only", 46: "full, operands L2-resident"}
+ARMS = {41: "full", 42: "mfma + barriers", 43: "no reads", 44: "no dma", 45: "dma only", 46: "full, operands L2-resident",
+        51: "four waves x 128x128"}
+if os.environ.get("GEMM_CLOCK_ONLY"):
+    ARMS = {int(v): ARMS[int(v)] for v in os.environ["GEMM_CLOCK_ONLY"].split(",")}
 out = []
 for dtype in ("bf16", "mxfp8"):
     s = 8192
