@@ -69,8 +69,9 @@ typedef struct {
 GMD_API int gmd_hbm_stream(int device, int kernel, uint64_t bytes_per_buffer, int iters, int nontemporal,
                            gmd_stream_result_t* out);
 /* One launch on caller buffers (float elements, 16-byte aligned, count a multiple of 4).
- * READ: `c`, when not NULL, receives one partial sum per workgroup and must hold
- * GMD_STREAM_SINK_FLOATS floats (the launch is then fully asynchronous). */
+ * READ: `c`, when not NULL, is a sink of GMD_STREAM_SINK_FLOATS floats into which every
+ * workgroup ADDS its sum (slot = workgroup index modulo the slot count); zero it beforehand if
+ * the total matters.  The launch is then fully asynchronous. */
 #define GMD_STREAM_SINK_FLOATS 32768
 GMD_API int gmd_hbm_stream_launch(int kernel, void* a, void* b, void* c, float scalar, uint64_t n_floats,
                                   int nontemporal, void* hip_stream);

@@ -2,10 +2,10 @@
 //
 // Six STREAM-style kernels.  Every lane moves 16 bytes per access (one
 // global_load/store_dwordx4, 1 KiB per wave-instruction — the widest coalesced
-// access the memory pipeline has).  The kernels that store give every lane one
-// access and let the in-order dispatch of a very large grid do the traversal
-// (onepass_kernel); the read kernel walks one contiguous span per workgroup with
-// kUnroll independent loads in flight (stream_kernel).  Buffers are sized far
+// access the memory pipeline has).  No kernel loops: the kernels that store give
+// every lane one access (onepass_kernel), the read kernel kUnroll independent loads
+// (read_kernel), and the in-order dispatch of a very large grid does the
+// traversal.  Buffers are sized far
 // beyond the 256 MiB Infinity Cache by the caller so the number reported is
 // HBM3E, not L3.  Non-temporal accesses keep the once-touched stream from
 // displacing lines in L2 / Infinity Cache; measured on MI355X they are worth
@@ -28,62 +28,6 @@ template <bool NT>
 __device__ __forceinline__ void st(f32x4* p, f32x4 v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
-}
-
-// One body for all kernels: OP selects what is loaded, computed and stored.
-// Traversal is block-contiguous: every workgroup owns one span of the buffers and
-// walks it front to back, its kUnroll accesses 4 KiB (one workgroup row) apart.
-// Measured on MI355X this beats a grid-stride walk (accesses a whole grid apart)
-// by 10-15 % on the kernels that store, and small spans (many workgroups) beat
-// few long ones.
-template <int OP, bool NT>
-__global__ __launch_bounds__(kBlock) void stream_kernel(f32x4* __restrict__ a, f32x4* __restrict__ b,
-                                                        f32x4* __restrict__ c, float s, uint64_t n4, uint64_t span,
-                                                        float* __restrict__ sink) {
-  uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x;
-  const uint64_t end = min((uint64_t)(blockIdx.x + 1) * span, n4);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (; i + (kUnroll - 1) * kBlock < end; i += kUnroll * kBlock) {
-    f32x4 x[kUnroll], y[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      const uint64_t j = i + u * kBlock;
-      if constexpr (OP == GMD_STREAM_COPY || OP == GMD_STREAM_ADD || OP == GMD_STREAM_READ) x[u] = ld<NT>(a + j);
-      if constexpr (OP == GMD_STREAM_ADD || OP == GMD_STREAM_TRIAD) y[u] = ld<NT>(b + j);
-      if constexpr (OP == GMD_STREAM_SCALE || OP == GMD_STREAM_TRIAD) x[u] = ld<NT>(c + j);
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      const uint64_t j = i + u * kBlock;
-      if constexpr (OP == GMD_STREAM_COPY) st<NT>(c + j, x[u]);
-      if constexpr (OP == GMD_STREAM_SCALE) st<NT>(b + j, s * x[u]);
-      if constexpr (OP == GMD_STREAM_ADD) st<NT>(c + j, x[u] + y[u]);
-      if constexpr (OP == GMD_STREAM_TRIAD) st<NT>(a + j, y[u] + s * x[u]);
-      if constexpr (OP == GMD_STREAM_READ) acc += x[u];
-      if constexpr (OP == GMD_STREAM_WRITE) st<NT>(a + j, f32x4{s, s, s, s});
-    }
-  }
-  for (; i < end; i += kBlock) {  // tail of the span
-    if constexpr (OP == GMD_STREAM_COPY) st<NT>(c + i, ld<NT>(a + i));
-    if constexpr (OP == GMD_STREAM_SCALE) st<NT>(b + i, s * ld<NT>(c + i));
-    if constexpr (OP == GMD_STREAM_ADD) st<NT>(c + i, ld<NT>(a + i) + ld<NT>(b + i));
-    if constexpr (OP == GMD_STREAM_TRIAD) st<NT>(a + i, ld<NT>(b + i) + s * ld<NT>(c + i));
-    if constexpr (OP == GMD_STREAM_READ) acc += ld<NT>(a + i);
-    if constexpr (OP == GMD_STREAM_WRITE) st<NT>(a + i, f32x4{s, s, s, s});
-  }
-  if constexpr (OP == GMD_STREAM_READ) {
-    // Reduce so the loads stay live; one float per block leaves the chip.
-    float t = acc.x + acc.y + acc.z + acc.w;
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-    __shared__ float part[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float r = 0;
-      for (int w = 0; w < kBlock / 64; w++) r += part[w];
-      sink[blockIdx.x] = r;
-    }
-  }
 }
 
 // The kernels that store run as ONE access per lane and nothing else: workgroup w
@@ -126,12 +70,45 @@ unsigned launch_onepass(f32x4* a, f32x4* b, f32x4* c, float s, uint64_t n4, hipS
   return grid;
 }
 
-constexpr unsigned kMaxGrid = gmd::kCUs * 128;  // READ: spans of >= 16 KiB; best measured point of the sweep
-static_assert(kMaxGrid <= GMD_STREAM_SINK_FLOATS, "a caller-provided READ sink must cover the grid");
+// The read stream in the same form: one unrolled pass (kUnroll independent 16-byte loads per lane, 16 KiB per
+// workgroup) and out.  The loads must stay live, so every workgroup adds its sum into one of
+// GMD_STREAM_SINK_FLOATS slots (one float atomic per 16 KiB read: far below the atomic rate).
+// Measured: 7.0 TB/s with 128 KiB spans -> 7.25 TB/s.
+static_assert((GMD_STREAM_SINK_FLOATS & (GMD_STREAM_SINK_FLOATS - 1)) == 0, "slot = workgroup & (slots - 1)");
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void read_kernel(const f32x4* __restrict__ a, uint64_t n4, float* __restrict__ sink) {
+  const uint64_t base = (uint64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x;
+  f32x4 x[kUnroll];
+#pragma unroll
+  for (int u = 0; u < kUnroll; u++) {
+    const uint64_t j = base + (uint64_t)u * kBlock;
+    x[u] = j < n4 ? ld<NT>(a + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 acc = (x[0] + x[1]) + (x[2] + x[3]);
+  static_assert(kUnroll == 4, "the sum above is written for four loads");
+  float t = acc.x + acc.y + acc.z + acc.w;
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  __shared__ float part[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = 0;
+    for (int w = 0; w < kBlock / 64; w++) r += part[w];
+    atomicAdd(sink + (blockIdx.x & (GMD_STREAM_SINK_FLOATS - 1)), r);
+  }
+}
 
-// Grid and span (in 16-byte elements, a multiple of one unrolled workgroup pass).
-inline void plan(uint64_t n4, unsigned* grid, uint64_t* span) {
-  gmd::span_plan(n4, (uint64_t)kBlock * kUnroll, kMaxGrid, grid, span);
+template <bool NT>
+unsigned launch_read(const f32x4* a, uint64_t n4, float* sink, hipStream_t st) {
+  constexpr uint64_t kPass = (uint64_t)kBlock * kUnroll;
+  constexpr uint64_t kPerLaunch = kPass << 23;  // grid x 256 work-items stays under 2^32: 128 GiB per launch
+  unsigned grid = 0;
+  for (uint64_t off = 0; off < n4; off += kPerLaunch) {
+    const uint64_t n = std::min(kPerLaunch, n4 - off);
+    grid = (unsigned)((n + kPass - 1) / kPass);
+    read_kernel<NT><<<grid, kBlock, 0, st>>>(a + off, n, sink);
+  }
+  return grid;
 }
 
 __global__ void init_kernel(f32x4* a, f32x4* b, f32x4* c, uint64_t n4) {
@@ -145,20 +122,15 @@ __global__ void init_kernel(f32x4* a, f32x4* b, f32x4* c, uint64_t n4) {
 
 template <bool NT>
 unsigned launch(int kernel, f32x4* a, f32x4* b, f32x4* c, float s, uint64_t n4, float* sink, hipStream_t st) {
-  unsigned grid = 0;
-  uint64_t span;
   switch (kernel) {
     case GMD_STREAM_COPY: return launch_onepass<GMD_STREAM_COPY, NT>(a, b, c, s, n4, st);
     case GMD_STREAM_SCALE: return launch_onepass<GMD_STREAM_SCALE, NT>(a, b, c, s, n4, st);
     case GMD_STREAM_ADD: return launch_onepass<GMD_STREAM_ADD, NT>(a, b, c, s, n4, st);
     case GMD_STREAM_TRIAD: return launch_onepass<GMD_STREAM_TRIAD, NT>(a, b, c, s, n4, st);
     case GMD_STREAM_WRITE: return launch_onepass<GMD_STREAM_WRITE, NT>(a, b, c, s, n4, st);
-    case GMD_STREAM_READ:  // one partial sum per workgroup: spans, so that the sink stays small
-      plan(n4, &grid, &span);
-      stream_kernel<GMD_STREAM_READ, NT><<<grid, kBlock, 0, st>>>(a, b, c, s, n4, span, sink);
-      break;
+    case GMD_STREAM_READ: return launch_read<NT>(a, n4, sink, st);
   }
-  return grid;
+  return 0;
 }
 
 // nontemporal: 0 = plain, 1 = non-temporal, 2 = the faster policy measured per kernel
@@ -190,14 +162,14 @@ int gmd_hbm_stream_launch(int kernel, void* a, void* b, void* c, float scalar, u
   if ((kernel == GMD_STREAM_SCALE) && (!b || !c)) return GMD_ERR_BADPARAM;
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return GMD_ERR_BADPARAM;
   hipStream_t st = (hipStream_t)hip_stream;
-  // READ leaves one partial sum per workgroup in a sink of GMD_STREAM_SINK_FLOATS floats:
-  // the caller's `c` when given (fully asynchronous), else a temporary (synchronises).
+  // READ adds every workgroup's sum into one of the GMD_STREAM_SINK_FLOATS slots of a sink: the caller's
+  // `c` when given (fully asynchronous; zero it first if the sums matter), else a temporary (synchronises).
   float* sink = nullptr;
   bool own_sink = false;
   if (kernel == GMD_STREAM_READ) {
     sink = (float*)c;
     if (!sink) {
-      GMD_HIP(hipMalloc((void**)&sink, sizeof(float) * kMaxGrid));
+      GMD_HIP(hipMalloc((void**)&sink, sizeof(float) * GMD_STREAM_SINK_FLOATS));
       own_sink = true;
     }
   }
@@ -225,7 +197,7 @@ int gmd_hbm_stream(int device, int kernel, uint64_t bytes_per_buffer, int iters,
   gmd::DeviceBuffer a, b, c, sink;
   int rc;
   if ((rc = a.alloc(bytes)) || (rc = b.alloc(bytes)) || (rc = c.alloc(bytes)) ||
-      (rc = sink.alloc(sizeof(float) * kMaxGrid)))
+      (rc = sink.alloc(sizeof(float) * GMD_STREAM_SINK_FLOATS)))
     return rc;
   init_kernel<<<gmd::kCUs * 8, 256>>>((f32x4*)a.p, (f32x4*)b.p, (f32x4*)c.p, n4);
   GMD_HIP(hipGetLastError());
@@ -236,6 +208,7 @@ int gmd_hbm_stream(int device, int kernel, uint64_t bytes_per_buffer, int iters,
     if (use_nt(kernel, nontemporal)) grid = launch<true>(kernel, (f32x4*)a.p, (f32x4*)b.p, (f32x4*)c.p, s, n4, (float*)sink.p, 0);
     else grid = launch<false>(kernel, (f32x4*)a.p, (f32x4*)b.p, (f32x4*)c.p, s, n4, (float*)sink.p, 0);
   };
+  GMD_HIP(hipMemset(sink.p, 0, sizeof(float) * GMD_STREAM_SINK_FLOATS));
   run();  // warm-up: page tables, clocks
   GMD_HIP(hipGetLastError());
   GMD_HIP(hipDeviceSynchronize());
@@ -277,12 +250,13 @@ int gmd_hbm_stream(int device, int kernel, uint64_t bytes_per_buffer, int iters,
       GMD_HIP(hipMemcpy(&v, (const float*)check + idx, sizeof v, hipMemcpyDeviceToHost));
       if (v != expect_val) out->verified = 0;
     }
-  } else {  // READ: the block sums must add up to n (every element is 1.0)
-    std::vector<float> part(kMaxGrid);
+  } else {  // READ: the slot sums must add up to n (every element is 1.0; slot sums are exact integers)
+    std::vector<float> part(GMD_STREAM_SINK_FLOATS);
     GMD_HIP(hipMemcpy(part.data(), sink.p, part.size() * sizeof(float), hipMemcpyDeviceToHost));
     double total = 0;
-    for (unsigned i = 0; i < grid; i++) total += part[i];
-    double want = (double)n4 * 4.0;
+    for (float p : part) total += p;
+    (void)grid;
+    double want = (double)n4 * 4.0 * (iters + 1);  // the warm-up and every timed launch added into it
     if (total < want * 0.999 || total > want * 1.001) out->verified = 0;
   }
   std::vector<float> sorted = ms;

@@ -47,7 +47,7 @@ __host__ __device__ __forceinline__ uint64_t expected_word(uint32_t pattern, uin
   return 0;
 }
 
-constexpr unsigned kMaxGrid = gmd::kCUs * 128;
+constexpr unsigned kVerifyMaxGrid = (1u << 24) - 1;
 
 // PAT is a compile-time constant so the pattern switch folds away; every workgroup
 // walks its own contiguous span (see gmd::span_plan).
@@ -147,9 +147,12 @@ void launch_fill(u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t pattern, 
 
 void launch_verify(const u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t pattern, uint64_t seed, VerifyOut* out,
                    hipStream_t st) {
+  // One unrolled pass (16 KiB) per workgroup up to 256 GiB per launch (grid x 256 work-items stays under
+  // 2^32), longer spans beyond: like the write pass, the in-order grid keeps the loads in flight in one
+  // compact window (+3 % over 128 workgroups per CU).
   unsigned grid;
   uint64_t span;
-  gmd::span_plan(n2, (uint64_t)kBlock * kUnroll, kMaxGrid, &grid, &span);
+  gmd::span_plan(n2, (uint64_t)kBlock * kUnroll, kVerifyMaxGrid, &grid, &span);
 #define CALL(P) verify_kernel<P><<<grid, kBlock, 0, st>>>(buf, n2, span, base_word, seed, out)
   GMD_FOR_PATTERN(pattern, CALL)
 #undef CALL
