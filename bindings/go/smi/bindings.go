@@ -164,6 +164,9 @@ func deviceProcesses(idx uint) ([]rawProcess, error) {
 	buf := make([]C.gm_process_t, C.GM_MAX_PROCS)
 	n := C.int(len(buf))
 	st := C.gm_smi_device_processes(C.uint32_t(idx), &buf[0], &n)
+	if st == C.GM_ST_NOT_SUPPORTED || st == C.GM_ST_NO_PERMISSION {
+		return nil, nil // no process table for this user: "none", like the other optional values
+	}
 	if st != C.GM_ST_OK && st != C.GM_ST_INSUFFICIENT_SIZE {
 		return nil, check("device processes", st)
 	}

@@ -134,6 +134,10 @@ struct Dev {
   uint64_t prev_res[5] = {0, 0, 0, 0, 0};
   bool have_prev = false;
   bool events_on = false;
+  // CU occupancy comes from the KFD process table, which costs a walk over /proc: read it at most once a
+  // second however fast the profiling fields are watched, and not at all where the table is not readable.
+  int64_t occupancy_read_mono = 0;
+  double occupancy = std::nan("");
 };
 
 std::string sysfs_trim(const std::string& path) {
@@ -237,6 +241,11 @@ class AmdSmiBackend : public Backend {
     out->clear();
     if (gpu >= devs_.size()) return GM_ST_BADPARAM;
     if (!api_.amdsmi_get_gpu_process_list) return GM_ST_NOT_SUPPORTED;
+    // The library builds its list from the KFD process table.  Where that directory is missing or closed
+    // (containers with a partial sysfs, non-root users on some hosts) it reports an EMPTY list as success
+    // and complains on stderr at every call: say what is true instead, and stay quiet.
+    static const int kfd_errno = access("/sys/class/kfd/kfd/proc", R_OK | X_OK) == 0 ? 0 : errno;
+    if (kfd_errno) return kfd_errno == EACCES ? GM_ST_NO_PERMISSION : GM_ST_NOT_SUPPORTED;
     uint32_t n = 64;
     std::vector<amdsmi_proc_info_t> list;
     amdsmi_status_t rc = AMDSMI_STATUS_SUCCESS;
@@ -714,17 +723,21 @@ class AmdSmiBackend : public Backend {
       if (!std::isnan(gr_active)) out->set_d(GM_FI_PROF_GR_ENGINE_ACTIVE, gr_active); else out->set_blank(GM_FI_PROF_GR_ENGINE_ACTIVE, GM_VS_NOT_SUPPORTED);
       if (valid(m.average_umc_activity)) out->set_d(GM_FI_PROF_HBM_ACTIVE, m.average_umc_activity); else out->set_blank(GM_FI_PROF_HBM_ACTIVE, GM_VS_NOT_SUPPORTED);
       // CU occupancy from the KFD process table: occupied CUs over all CUs.
-      std::vector<ProcSample> ps;
-      if (d.st.num_cu && processes(d.st.index, &ps) == GM_ST_OK) {
-        uint64_t cu = 0;
-        bool any = false;
-        for (auto& p : ps)
-          if (valid(p.cu_occupancy)) { cu += p.cu_occupancy; any = true; }
-        if (any || ps.empty()) out->set_d(GM_FI_PROF_CU_OCCUPANCY, std::min(100.0, 100.0 * (double)cu / d.st.num_cu));
-        else out->set_blank(GM_FI_PROF_CU_OCCUPANCY, GM_VS_NOT_SUPPORTED);
-      } else {
-        out->set_blank(GM_FI_PROF_CU_OCCUPANCY, GM_VS_NOT_SUPPORTED);
+      const int64_t now = monotonic_us();
+      if (!d.occupancy_read_mono || now - d.occupancy_read_mono >= 1000000) {
+        d.occupancy_read_mono = now;
+        d.occupancy = std::nan("");
+        std::vector<ProcSample> ps;
+        if (d.st.num_cu && processes(d.st.index, &ps) == GM_ST_OK) {
+          uint64_t cu = 0;
+          bool any = false;
+          for (auto& p : ps)
+            if (valid(p.cu_occupancy)) { cu += p.cu_occupancy; any = true; }
+          if (any || ps.empty()) d.occupancy = std::min(100.0, 100.0 * (double)cu / d.st.num_cu);
+        }
       }
+      if (!std::isnan(d.occupancy)) out->set_d(GM_FI_PROF_CU_OCCUPANCY, d.occupancy);
+      else out->set_blank(GM_FI_PROF_CU_OCCUPANCY, GM_VS_NOT_SUPPORTED);
       // Wave-level CU activity and MFMA pipe activity need device-wide hardware
       // counters, which this backend does not program: blank, not estimated.
       out->set_blank(GM_FI_PROF_CU_ACTIVE, GM_VS_NOT_SUPPORTED);

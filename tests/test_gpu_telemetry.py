@@ -151,9 +151,13 @@ def test_own_process_is_attributed(hw):
     gpu = _engine_index_of_hip0()
     keep = torch.ones(1 << 28, device="cuda:0")  # 1 GiB
     torch.cuda.synchronize()
-    procs = E.device_processes(gpu)
+    try:
+        procs = E.device_processes(gpu)
+    except E.GpumonError as e:
+        assert e.status in (A.GM_ST_NOT_SUPPORTED, A.GM_ST_NO_PERMISSION), e
+        pytest.skip("the driver exposes no per-process table to this user (reported as such, not as an empty list)")
     if not procs:
-        pytest.skip("the driver exposes no per-process table to this user")
+        pytest.skip("the process table is readable but empty")
     mine = [p for p in procs if p["pid"] == os.getpid()]
     assert mine and mine[0]["vram_bytes"] >= 1 << 30
     del keep
