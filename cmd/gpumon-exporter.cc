@@ -16,6 +16,7 @@
 //   --pod-map FILE   pod map fallback (TSV or kubelet device-plugin checkpoint)
 //   --resource NAMES device-plugin resource names (default amd.com/gpu)
 //   --diag-results PATH   export the report(s) left by `gpumon-diag --publish` as gpumon_diag_* metrics
+//   --state-file PATH     keep the gpu_last_not_idle_time latch across restarts
 //   --legacy-layout  GPU-major output exactly like the reference's awk program
 //   --once           one sweep, then exit
 //   -connect ADDR [-socket]   use a running gpumon-hostengine instead of -e
@@ -49,7 +50,7 @@ int main(int argc, char** argv) {
     return 1;
   }
   bool embedded = false, profiling = false, once = false, extras = false, self = false, rest = false, legacy = false;
-  std::string out = "/run/prometheus/dcgm.prom", listen, gpus, kubelet, podmap, resource, diagres;
+  std::string out = "/run/prometheus/dcgm.prom", listen, gpus, kubelet, podmap, resource, diagres, statefile;
   long interval = 1000;
   for (size_t i = 0; i < args.size(); i++) {
     const std::string& a = args[i];
@@ -75,6 +76,7 @@ int main(int argc, char** argv) {
     else if (a == "--pod-map") val(&podmap);
     else if (a == "--resource") val(&resource);
     else if (a == "--diag-results") val(&diagres);
+    else if (a == "--state-file") val(&statefile);
     else if (a == "--legacy-layout") legacy = true;
     else if (a == "--once") once = true;
     else { usage(argv[0]); return 1; }
@@ -129,6 +131,7 @@ int main(int argc, char** argv) {
   cfg.kubelet_socket = kubelet.empty() ? nullptr : kubelet.c_str();
   cfg.pod_map_path = podmap.empty() ? nullptr : podmap.c_str();
   cfg.diag_results_path = diagres.empty() ? nullptr : diagres.c_str();
+  cfg.state_path = statefile.empty() ? nullptr : statefile.c_str();
   cfg.resource_names = resource.empty() ? nullptr : resource.c_str();
   gm_exporter_t ex;
   CLI_CHECK(gm_exporter_create(&cfg, &ex));

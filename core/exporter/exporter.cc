@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include "../common/json.h"
 #include "../common/util.h"
 
 namespace gpumon {
@@ -97,6 +98,7 @@ Exporter::Exporter(Engine* engine, const ExporterConfig& cfg) : engine_(engine),
 
 Exporter::~Exporter() {
   stop();
+  save_state(true);
   if (watching_) {
     engine_->unwatch_fields(group_, fg_);
     engine_->field_group_destroy(fg_);
@@ -154,7 +156,59 @@ gm_status_t Exporter::init() {
   watching_ = true;
   if (cfg_.self_metrics) engine_->introspect_toggle(true);
   if (!cfg_.pod_map_path.empty() || !cfg_.kubelet_socket.empty()) refresh_pod_map();
+  load_state();
   return GM_ST_OK;
+}
+
+// ---- state carried across restarts ----------------------------------------------
+// Everything the GPUs count themselves (energy, ECC, violation accumulators) survives
+// an exporter restart on its own.  The one value the exporter accumulates is the
+// gpu_last_not_idle_time latch, which the reference's awk script starts at "now" on
+// every start (dcgm-exporter:97-113): an idle-GPU reaper that reads it sees a GPU
+// "become busy" whenever systemd restarts the exporter.  With a state path the latch
+// is kept per GPU UUID, written atomically at most every 10 s and at shutdown.
+void Exporter::load_state() {
+  if (cfg_.state_path.empty()) return;
+  std::string text;
+  Json j;
+  if (!read_file(cfg_.state_path, &text)) return;  // first start
+  if (!json_parse(text, &j) || j.type != Json::OBJ) {
+    GM_LOGW("exporter: ignoring unreadable state file %s", cfg_.state_path.c_str());
+    return;
+  }
+  const Json* latch = j.get("last_not_idle");
+  if (!latch || latch->type != Json::OBJ) return;
+  const int64_t now_s = now_us() / 1000000;
+  std::lock_guard<std::mutex> l(mu_);
+  for (size_t g = 0; g < gpus_.size(); g++) {
+    const Json* v = latch->get(uuids_[g]);
+    if (!v || v->type != Json::NUM) continue;
+    const int64_t ts = (int64_t)v->num;
+    if (ts > 0 && ts <= now_s) last_not_idle_[gpus_[g]] = ts;  // a timestamp from the future is a clock step: start over
+  }
+}
+
+void Exporter::save_state(bool force) {
+  if (cfg_.state_path.empty()) return;
+  std::string text;
+  {
+    std::lock_guard<std::mutex> l(mu_);
+    const int64_t now = monotonic_us();
+    if (!state_dirty_ || (!force && state_saved_mono_ && now - state_saved_mono_ < 10000000)) return;
+    text = "{\"version\":1,\"last_not_idle\":{";
+    bool first = true;
+    for (size_t g = 0; g < gpus_.size(); g++) {
+      auto it = last_not_idle_.find(gpus_[g]);
+      if (it == last_not_idle_.end() || uuids_[g].empty()) continue;
+      text += strprintf("%s\"%s\":%lld", first ? "" : ",", json_escape(uuids_[g]).c_str(), (long long)it->second);
+      first = false;
+    }
+    text += "}}\n";
+    state_dirty_ = false;
+    state_saved_mono_ = now;
+  }
+  if (!write_file_atomic(cfg_.state_path, text.data(), text.size()))
+    GM_LOGW("exporter: cannot write state file %s: %s", cfg_.state_path.c_str(), strerror(errno));
 }
 
 void Exporter::set_pod_map(const PodMap& m) {
@@ -245,7 +299,10 @@ void Exporter::render(std::string* out) {
     if (fam.last_not_idle) {
       int64_t util = v->type == GM_FT_DOUBLE ? (int64_t)v->v.dbl : v->v.i64;
       auto it = last_not_idle_.find(gpus_[g]);
-      if (it == last_not_idle_.end() || util > 2) last_not_idle_[gpus_[g]] = now_s;
+      if (it == last_not_idle_.end() || util > 2) {
+        if (it == last_not_idle_.end() || it->second != now_s) state_dirty_ = true;
+        last_not_idle_[gpus_[g]] = now_s;
+      }
       *out += strprintf("%lld", (long long)last_not_idle_[gpus_[g]]);
     } else {
       append_value(out, *v);
@@ -326,6 +383,7 @@ gm_status_t Exporter::publish() {
   }
   sweeps_++;
   last_sweep_us_ = now_us();
+  save_state(false);
   return GM_ST_OK;
 }
 

@@ -50,6 +50,7 @@ struct ExporterConfig {
   std::string resource_names = "amd.com/gpu";
   std::string pod_map_path;
   std::string diag_results_path;  // report(s) of gpumon-diag --publish, rendered as gpumon_diag_* families
+  std::string state_path;         // carries the last-not-idle latch across restarts ("" = in memory only)
 };
 
 class Exporter {
@@ -71,6 +72,8 @@ class Exporter {
   void refresh_pod_map();
   void handle_http(const HttpRequest& req, HttpResponse* resp);
   void render_self(std::string* out);
+  void load_state();
+  void save_state(bool force);
 
   Engine* engine_;
   ExporterConfig cfg_;
@@ -83,6 +86,8 @@ class Exporter {
 
   std::mutex mu_;  // last_not_idle_, pod_map_, cached text
   std::map<uint32_t, int64_t> last_not_idle_;
+  bool state_dirty_ = false;
+  int64_t state_saved_mono_ = 0;
   PodMap pod_map_;
   std::string cached_;  // last published text (served over HTTP between sweeps)
   std::vector<gm_value_t> scratch_;

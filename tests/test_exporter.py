@@ -172,6 +172,44 @@ def test_last_not_idle_time_latches(engine2):
         assert t3["1"] == t2["1"]
 
 
+def test_last_not_idle_latch_survives_a_restart(engine2, tmp_path):
+    """What the exporter accumulates itself is carried in a state file keyed by GPU UUID; the reference's
+    awk script starts the latch at "now" on every start (dcgm-exporter:97-113)."""
+    import json
+    state = tmp_path / "state" / "exporter.json"
+    state.parent.mkdir()
+
+    def latch(ex):
+        ex.sweep()
+        return {l["uuid"]: v for l, v in parse(ex.render())["dcgm_gpu_last_not_idle_time"].samples}
+
+    with E.Exporter(state_path=str(state)) as ex:
+        first = latch(ex)
+    saved = json.loads(state.read_text())  # written at shutdown even though the 10 s save period has not passed
+    assert saved["version"] == 1 and saved["last_not_idle"] == {u: int(v) for u, v in first.items()}
+    time.sleep(1.1)
+    with E.Exporter(state_path=str(state)) as ex:
+        assert latch(ex) == first  # idle GPUs: the stamps of the previous run hold
+        E.fake_ctl("load gpu=0 util=80")
+        time.sleep(1.1)
+        busy = latch(ex)
+        uuid0 = E.device_attributes(0)["uuid"]
+        assert busy[uuid0] > first[uuid0] and all(busy[u] == first[u] for u in first if u != uuid0)
+    E.fake_ctl("load gpu=0 util=0")
+    assert json.loads(state.read_text())["last_not_idle"][uuid0] == int(busy[uuid0])
+    # a stamp from the future (clock stepped back) and a damaged file both mean "start over", never a crash
+    state.write_text(json.dumps({"version": 1, "last_not_idle": {uuid0: int(time.time()) + 10 ** 6}}))
+    with E.Exporter(state_path=str(state)) as ex:
+        assert abs(latch(ex)[uuid0] - time.time()) < 5
+    state.write_text("{broken")
+    with E.Exporter(state_path=str(state)) as ex:
+        assert abs(latch(ex)[uuid0] - time.time()) < 5
+    # without a state path nothing is written
+    with E.Exporter() as ex:
+        latch(ex)
+    assert sorted(p.name for p in state.parent.iterdir()) == ["exporter.json"]
+
+
 def test_gpu_subset_and_bad_subset(engine):
     with E.Exporter(interval_ms=1000, gpus="5,2") as ex:
         ex.sweep()
