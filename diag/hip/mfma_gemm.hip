@@ -1008,9 +1008,11 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
   const size_t esz = fp8 ? 1 : 2;
   gmd::DeviceBuffer a, b, c, sums;
   int rc;
-  const int kMaxLaunches = 1 << 16;
+  // Checksums land in a window of slots that is drained to the host (compared, cleared) whenever it is
+  // full, so the soak runs for as long as it is asked to.
+  const int kWindow = 1 << 13;
   if ((rc = a.alloc((size_t)m * k * esz)) || (rc = b.alloc((size_t)n * k * esz)) || (rc = c.alloc((size_t)m * n * 2)) ||
-      (rc = sums.alloc(sizeof(unsigned long long) * kMaxLaunches)))
+      (rc = sums.alloc(sizeof(unsigned long long) * kWindow)))
     return rc;
   if (fp8) {
     fill_fp8_kernel<<<2048, 256>>>((uint8_t*)a.p, (uint64_t)m * k, 1);
@@ -1019,7 +1021,7 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
     fill_bf16_kernel<<<2048, 256>>>((__bf16*)a.p, (uint64_t)m * k, 1);
     fill_bf16_kernel<<<2048, 256>>>((__bf16*)b.p, (uint64_t)n * k, 2);
   }
-  GMD_HIP(hipMemset(sums.p, 0, sizeof(unsigned long long) * kMaxLaunches));
+  GMD_HIP(hipMemset(sums.p, 0, sizeof(unsigned long long) * kWindow));
   GMD_HIP(hipGetLastError());
   if ((rc = gmd_gemm_launch(dtype, a.p, b.p, c.p, m, n, k, nullptr))) return rc;  // warm-up
   GMD_HIP(hipDeviceSynchronize());
@@ -1030,23 +1032,38 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
   GMD_HIP(hipEventCreate(&e1));
   const double flops = 2.0 * m * n * (double)k;
   double t_start = now_s(), gpu_s = 0, best_ms = 1e30;
-  uint64_t launches = 0;
-  while (launches < (uint64_t)kMaxLaunches) {
+  uint64_t launches = 0, in_window = 0;
+  unsigned long long ref_sum = 0;
+  bool have_ref = false;
+  std::vector<unsigned long long> h(kWindow);
+  auto drain = [&]() -> int {  // device idle: compare the window against the first launch's checksum, clear it
+    if (!verify || !in_window) return GMD_OK;
+    GMD_HIP(hipMemcpy(h.data(), sums.p, in_window * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (!have_ref) ref_sum = h[0], have_ref = true;
+    for (uint64_t i = 0; i < in_window; i++)
+      if (h[i] != ref_sum) out->sdc_mismatches++;
+    GMD_HIP(hipMemset(sums.p, 0, in_window * sizeof(unsigned long long)));
+    in_window = 0;
+    return GMD_OK;
+  };
+  for (;;) {
     // Batches of launches between host syncs keep the queue full.
     const int batch = 8;
     GMD_HIP(hipEventRecord(e0, 0));
     for (int i = 0; i < batch; i++) {
       if ((rc = gmd_gemm_launch(dtype, a.p, b.p, c.p, m, n, k, nullptr))) return rc;
-      if (verify) checksum_kernel<<<1024, 256>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + launches + i);
+      if (verify) checksum_kernel<<<1024, 256>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + in_window + i);
     }
     GMD_HIP(hipEventRecord(e1, 0));
     GMD_HIP(hipEventSynchronize(e1));
     float ms = 0;
     GMD_HIP(hipEventElapsedTime(&ms, e0, e1));
     launches += batch;
+    in_window += batch;
     gpu_s += ms * 1e-3;
     best_ms = std::min(best_ms, (double)ms / batch);
-    if (now_s() - t_start >= seconds || launches + batch > (uint64_t)kMaxLaunches) break;
+    if (in_window + batch > (uint64_t)kWindow && (rc = drain())) return rc;
+    if (now_s() - t_start >= seconds) break;
   }
   GMD_HIP(hipGetLastError());
   (void)hipEventDestroy(e0);
@@ -1056,12 +1073,9 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
   out->tflops = flops * (double)launches / gpu_s / 1e12;
   out->tflops_best = flops / (best_ms * 1e-3) / 1e12;
   if (verify) {
-    std::vector<unsigned long long> h(launches);
-    GMD_HIP(hipMemcpy(h.data(), sums.p, launches * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (uint64_t i = 1; i < launches; i++)
-      if (h[i] != h[0]) out->sdc_mismatches++;
+    if ((rc = drain())) return rc;
     out->verified = out->sdc_mismatches ? -1 : 1;
-    if (h[0] == 0) out->verified = -1;  // an all-zero C means the kernel did nothing
+    if (ref_sum == 0) out->verified = -1;  // an all-zero C means the kernel did nothing
   }
   if (out->verified < 0) {
     gmd::set_error("GEMM stress: %llu of %llu launches differ from the first (silent data corruption?)",
