@@ -90,6 +90,22 @@ func driverVersion() (string, error) {
 	return C.GoString(&buf[0]), nil
 }
 
+// runtimeVersion: ROCm release under the device library; nil, nil when it cannot be told
+// (the reference maps NVML_ERROR_NOT_SUPPORTED the same way, bindings/go/nvml/bindings.go:152-165).
+func runtimeVersion() (*uint, *uint, string, error) {
+	var major, minor C.uint32_t
+	var buf [C.GM_STR_LEN]C.char
+	st := C.gm_smi_runtime_version(&major, &minor, &buf[0], C.size_t(len(buf)))
+	if st == C.GM_ST_NOT_SUPPORTED {
+		return nil, nil, "", nil
+	}
+	if err := check("runtime version", st); err != nil {
+		return nil, nil, "", err
+	}
+	ma, mi := uint(major), uint(minor)
+	return &ma, &mi, C.GoString(&buf[0]), nil
+}
+
 type rawAttributes struct {
 	supported                              bool
 	uuid, name, brand, serial, vbios       string

@@ -4,6 +4,7 @@ import (
 	"errors"
 	"fmt"
 	"math"
+	"strconv"
 	"strings"
 	"time"
 )
@@ -157,6 +158,38 @@ func Shutdown() error { return shutdownLib() }
 func GetDeviceCount() (uint, error) { return deviceCount() }
 
 func GetDriverVersion() (string, error) { return driverVersion() }
+
+// GetRuntimeVersion returns major and minor of the ROCm release the device library belongs to, the
+// counterpart of nvml.GetCudaDriverVersion (bindings/go/nvml/nvml.go:290-292); nil, nil when unknown.
+func GetRuntimeVersion() (*uint, *uint, error) {
+	major, minor, _, err := runtimeVersion()
+	return major, minor, err
+}
+
+// GfxVersionInfo is the compute-capability analog (bindings/go/nvml/nvml.go:196-199): gfx950 is
+// {9, 5, 0}, gfx90a is {9, 0, 10}.  Nil members when the target string is not of that form.
+type GfxVersionInfo struct {
+	Major, Minor, Stepping *int
+}
+
+// GfxVersion parses Device.GfxTarget.
+func (d *Device) GfxVersion() GfxVersionInfo {
+	t := d.GfxTarget
+	if i := strings.IndexByte(t, ':'); i >= 0 {
+		t = t[:i]
+	}
+	if !strings.HasPrefix(t, "gfx") || len(t) < 6 {
+		return GfxVersionInfo{}
+	}
+	major, e1 := strconv.ParseInt(t[3:len(t)-2], 10, 32)
+	minor, e2 := strconv.ParseInt(t[len(t)-2:len(t)-1], 16, 32)
+	step, e3 := strconv.ParseInt(t[len(t)-1:], 16, 32)
+	if e1 != nil || e2 != nil || e3 != nil {
+		return GfxVersionInfo{}
+	}
+	ma, mi, st := int(major), int(minor), int(step)
+	return GfxVersionInfo{&ma, &mi, &st}
+}
 
 func optUint(v int64, ok bool) *uint {
 	if !ok || v < 0 {

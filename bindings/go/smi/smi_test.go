@@ -46,6 +46,15 @@ func TestFakeDeviceCountAndInfo(t *testing.T) {
 	if len(d.Topology) != 3 || d.Topology[0].Name != "XGMI1" {
 		t.Errorf("topology: %+v", d.Topology)
 	}
+	if v := d.GfxVersion(); v.Major == nil || *v.Major != 9 || *v.Minor != 5 || *v.Stepping != 0 {
+		t.Errorf("gfx version of %q: %+v", d.GfxTarget, v)
+	}
+	if v := (&Device{GfxTarget: "gfx90a:sramecc+:xnack-"}).GfxVersion(); v.Major == nil || *v.Major != 9 || *v.Minor != 0 || *v.Stepping != 10 {
+		t.Errorf("gfx90a: %+v", v)
+	}
+	if major, minor, err := GetRuntimeVersion(); err != nil || major == nil || *major != 7 || *minor != 2 {
+		t.Errorf("runtime version: %v %v %v", major, minor, err)
+	}
 	lite, err := NewDeviceLite(2)
 	if err != nil || lite.UUID != d.UUID || lite.Power != nil || lite.Topology != nil {
 		t.Errorf("lite: %+v %v", lite, err)

@@ -43,6 +43,7 @@ namespace {
   X(amdsmi_get_gpu_board_info, 0)                     \
   X(amdsmi_get_gpu_vbios_info, 0)                     \
   X(amdsmi_get_gpu_driver_info, 0)                    \
+  X(amdsmi_get_lib_version, 0)                        \
   X(amdsmi_get_fw_info, 0)                            \
   X(amdsmi_get_gpu_kfd_info, 0)                       \
   X(amdsmi_get_power_cap_info, 0)                     \
@@ -223,6 +224,33 @@ class AmdSmiBackend : public Backend {
   void refresh_handles() override {
     std::lock_guard<std::mutex> l(mu_);
     if (inited_) enumerate();
+  }
+
+  // The ROCm release that the loaded device library belongs to (<prefix>/.info/version next to its lib
+  // directory), else the library's own version.
+  gm_status_t runtime_version(uint32_t* major, uint32_t* minor, std::string* text) override {
+    std::string v;
+    Dl_info info;
+    if (api_.amdsmi_init && dladdr(reinterpret_cast<void*>(api_.amdsmi_init), &info) && info.dli_fname) {
+      char real[PATH_MAX];
+      std::string path = realpath(info.dli_fname, real) ? real : info.dli_fname;
+      const size_t file = path.rfind('/');  // <prefix>/lib/libamd_smi.so.N -> <prefix>
+      const size_t dir = file != std::string::npos && file > 0 ? path.rfind('/', file - 1) : std::string::npos;
+      if (dir != std::string::npos && read_file(path.substr(0, dir) + "/.info/version", &v)) v = trim(v);
+      else v.clear();
+    }
+    unsigned a = 0, b = 0;
+    if (!v.empty() && sscanf(v.c_str(), "%u.%u", &a, &b) == 2) {
+      *major = a, *minor = b, *text = v;
+      return GM_ST_OK;
+    }
+    if (!api_.amdsmi_get_lib_version) return GM_ST_NOT_SUPPORTED;
+    amdsmi_version_t lv;
+    memset(&lv, 0, sizeof lv);
+    if (api_.amdsmi_get_lib_version(&lv) != AMDSMI_STATUS_SUCCESS) return GM_ST_NOT_SUPPORTED;
+    *major = lv.major, *minor = lv.minor;
+    *text = strprintf("amdsmi %u.%u.%u", lv.major, lv.minor, lv.release);
+    return GM_ST_OK;
   }
 
   gm_status_t sample(uint32_t gpu, uint32_t sources, Sample* out) override {

@@ -130,6 +130,13 @@ class Backend {
   virtual gm_status_t control(const std::string& command) { (void)command; return GM_ST_NOT_SUPPORTED; }
   // Re-enumerate after a GPU reset.
   virtual void refresh_handles() {}
+  // Version of the user-space stack under the backend: the ROCm release when it can be found, else the
+  // device library's own version (the counterpart of the reference's CUDA driver version,
+  // bindings/go/nvml/bindings.go:152-165).  `text` is the full string, e.g. "7.2.0" or "amdsmi 26.2.0".
+  virtual gm_status_t runtime_version(uint32_t* major, uint32_t* minor, std::string* text) {
+    (void)major, (void)minor, (void)text;
+    return GM_ST_NOT_SUPPORTED;
+  }
 };
 
 std::unique_ptr<Backend> make_fake_backend(const std::string& spec);

@@ -330,6 +330,11 @@ class FakeBackend : public Backend {
     return GM_ST_OK;
   }
 
+  gm_status_t runtime_version(uint32_t* major, uint32_t* minor, std::string* text) override {
+    *major = 7, *minor = 2, *text = "7.2.0";
+    return GM_ST_OK;
+  }
+
   // "<verb> key=value key=value ..." (keys may also be separated by commas).
   gm_status_t control(const std::string& command) override {
     std::string c = command;

@@ -99,6 +99,17 @@ gm_status_t gm_smi_driver_version(char* buf, size_t cap) {
   return GM_ST_OK;
 }
 
+gm_status_t gm_smi_runtime_version(uint32_t* major, uint32_t* minor, char* buf, size_t cap) {
+  Smi& s = S();
+  SMI_READY(s);
+  if (!major || !minor) return GM_ST_BADPARAM;
+  std::string text;
+  std::lock_guard<std::mutex> l(s.call_mu);
+  gm_status_t st = s.be->runtime_version(major, minor, &text);
+  if (st == GM_ST_OK && buf && cap) copy_str(buf, cap, text);
+  return st;
+}
+
 gm_status_t gm_smi_device_attributes(uint32_t gpu, gm_device_attributes_t* out) {
   Smi& s = S();
   SMI_READY(s);

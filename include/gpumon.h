@@ -752,6 +752,9 @@ GM_API gm_status_t gm_smi_init(const char* backend /* NULL = "amdsmi" */, const 
 GM_API gm_status_t gm_smi_shutdown(void);
 GM_API gm_status_t gm_smi_device_count(uint32_t* count);
 GM_API gm_status_t gm_smi_driver_version(char* buf, size_t cap);
+/* Version of the user-space stack: the ROCm release the device library belongs to ("7.2.0"), else the
+ * library's own version; buf may be NULL.  The counterpart of nvml.GetCudaDriverVersion. */
+GM_API gm_status_t gm_smi_runtime_version(uint32_t* major, uint32_t* minor, char* buf, size_t cap);
 GM_API gm_status_t gm_smi_device_attributes(uint32_t gpu, gm_device_attributes_t* out);
 /* One synchronous read of everything gm_device_status_t holds. */
 GM_API gm_status_t gm_smi_device_status(uint32_t gpu, gm_device_status_t* out);

@@ -57,8 +57,29 @@ class Device:
         return device_status(self.index, api=self.api)
 
     def processes(self) -> List["ProcessInfo"]:
-        return [ProcessInfo(p["pid"], p["name"], p["vram_bytes"] >> 20, "C")
-                for p in self.api.device_processes(self.index)]
+        """Empty where the process table cannot be read by this user (reported as not supported)."""
+        from .._lib import GpumonError
+        from .. import abi as A
+        try:
+            procs = self.api.device_processes(self.index)
+        except GpumonError as e:
+            if e.status in (A.GM_ST_NOT_SUPPORTED, A.GM_ST_NO_PERMISSION):
+                return []
+            raise
+        return [ProcessInfo(p["pid"], p["name"], p["vram_bytes"] >> 20, "C") for p in procs]
+
+    @property
+    def gfx_version(self):
+        """(major, minor, stepping) of the gfx target — gfx950 -> (9, 5, 0), gfx90a -> (9, 0, 10) — the
+        counterpart of the reference's CudaComputeCapability (bindings/go/nvml/nvml.go:196-199); None
+        when the target is unknown."""
+        t = (self.gfx_target or "").split(":")[0]
+        if not t.startswith("gfx") or len(t) < 6:
+            return None
+        try:
+            return int(t[3:-2]), int(t[-2], 16), int(t[-1], 16)
+        except ValueError:
+            return None
 
 
 @dataclass

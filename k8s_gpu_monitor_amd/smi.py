@@ -26,6 +26,7 @@ def _L():
         sig = {
             "gm_smi_init": [C.c_char_p, C.c_char_p], "gm_smi_shutdown": [], "gm_smi_device_count": [u32p],
             "gm_smi_driver_version": [C.c_char_p, C.c_size_t],
+            "gm_smi_runtime_version": [u32p, u32p, C.c_char_p, C.c_size_t],
             "gm_smi_device_attributes": [C.c_uint32, C.POINTER(A.DeviceAttributes)],
             "gm_smi_device_status": [C.c_uint32, C.POINTER(A.DeviceStatus)],
             "gm_smi_read_fields": [C.c_uint32, C.POINTER(C.c_uint16), C.c_int, C.POINTER(A.Value)],
@@ -72,6 +73,18 @@ def driver_version():
     buf = C.create_string_buffer(A.GM_STR_LEN)
     check(_L().gm_smi_driver_version(buf, len(buf)), "smi.driver_version")
     return buf.value.decode()
+
+
+def runtime_version():
+    """(major, minor, text) of the ROCm release under the device library, or None when unknown: the
+    counterpart of nvml.GetCudaDriverVersion (bindings/go/nvml/nvml.go:290-292)."""
+    major, minor = C.c_uint32(), C.c_uint32()
+    buf = C.create_string_buffer(A.GM_STR_LEN)
+    st = _L().gm_smi_runtime_version(C.byref(major), C.byref(minor), buf, len(buf))
+    if st == A.GM_ST_NOT_SUPPORTED:
+        return None
+    check(st, "smi.runtime_version")
+    return major.value, minor.value, buf.value.decode()
 
 
 def _struct_dict(s, skip=("version",)):

@@ -176,6 +176,13 @@ def test_static_fields_match_amd_smi_exactly(hw):
     smi.init(backend="amdsmi")
     try:
         assert smi.device_count() == len(listing)
+        rt = smi.runtime_version()  # the ROCm release the device library was loaded from
+        assert rt is not None and rt[0] >= 6
+        info = "/opt/rocm/.info/version"
+        if os.path.exists(info):
+            assert open(info).read().strip().startswith(f"{rt[0]}.{rt[1]}"), rt
+        from k8s_gpu_monitor_amd.models import device as M
+        assert M.new_device(0, lite=True, api=smi).gfx_version == (9, 5, 0)
         for i, row in enumerate(listing):
             ours, direct = E.device_attributes(i), smi.device_attributes(i)
             # both layers read the same attribute cache code; the clock ceiling is reported by the firmware

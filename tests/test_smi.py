@@ -48,6 +48,7 @@ def test_lifetime_is_refcounted_and_independent_of_the_engine():
 def test_direct_reads(direct):
     assert smi.device_count() == 4
     assert smi.driver_version().startswith("6.")
+    assert smi.runtime_version() == (7, 2, "7.2.0")  # the CUDA-driver-version analog
     a = smi.device_attributes(2)
     assert a["name"] == "AMD Instinct MI355X" and a["uuid"].endswith("02") and a["num_cu"] == 256
     s = smi.device_status(2)
@@ -106,6 +107,11 @@ def test_data_model_on_both_layers(direct):
     assert d.model == "AMD Instinct MI355X" and d.path.startswith("/dev/dri/renderD") and d.memory == 294896
     assert d.power == 1400 and d.clocks.cores == 2400 and d.pci.bandwidth == 63008  # Gen5 x16: 3938 MB/s per lane
     assert [t.link for t in d.topology] == ["XGMI1"] * 3
+    assert d.gfx_target == "gfx950" and d.gfx_version == (9, 5, 0)  # the compute-capability analog
+    import dataclasses
+    assert dataclasses.replace(d, gfx_target="gfx90a:sramecc+:xnack-").gfx_version == (9, 0, 10)
+    assert dataclasses.replace(d, gfx_target=None).gfx_version is None
+    assert d.processes() == []
     lite = M.new_device(1, lite=True, api=smi)
     assert lite.uuid == d.uuid and lite.power is None and lite.memory is None and lite.topology == []
     st = d.status()
