@@ -55,7 +55,7 @@ func main() {
 					if p.CUOccupancy != nil {
 						cus = fmt.Sprint(*p.CUOccupancy)
 					}
-					fmt.Printf("%5d %5d %5s %5d %4s  %s\n", i, p.PID, "C", p.MemoryUsed, cus, p.Name)
+					fmt.Printf("%5d %5d %5s %5d %4s  %s\n", i, p.PID, p.Type, p.MemoryUsed, cus, p.Name)
 				}
 			}
 		case <-stop:

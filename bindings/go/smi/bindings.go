@@ -217,13 +217,20 @@ func peerLink(a, b uint) (*rawPeerLink, error) {
 func linkName(link, hops uint) string { return C.GoString(C.gm_link_type_name(C.int32_t(link), C.uint32_t(hops))) }
 func linkDescription(link uint) string { return C.GoString(C.gm_link_type_description(C.int32_t(link))) }
 
-func deviceMode(idx uint) (compute, memory string, err error) {
+type rawMode struct {
+	compute, memory      string
+	accountingOn         bool
+	accountingBufferSize uint
+}
+
+func deviceMode(idx uint) (rawMode, error) {
 	var m C.gm_device_mode_t
 	C.smi_mode_init(&m)
-	if err = check("device mode", C.gm_smi_device_mode(C.uint32_t(idx), &m)); err != nil {
-		return
+	if err := check("device mode", C.gm_smi_device_mode(C.uint32_t(idx), &m)); err != nil {
+		return rawMode{}, err
 	}
-	return C.GoString(&m.compute_partition[0]), C.GoString(&m.memory_partition[0]), nil
+	return rawMode{compute: C.GoString(&m.compute_partition[0]), memory: C.GoString(&m.memory_partition[0]),
+		accountingOn: m.accounting_enabled != 0, accountingBufferSize: uint(m.accounting_buffer_size)}, nil
 }
 
 type rawEvent struct {

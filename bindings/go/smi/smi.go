@@ -105,10 +105,31 @@ type PCIThroughputInfo struct {
 	TX *uint
 }
 
+// ProcessType keeps the reference's three kinds (nvml.go:113-131).  KFD processes are compute
+// processes; an MI355X has no graphics queue, so Graphics never occurs on it.
+type ProcessType uint
+
+const (
+	Compute ProcessType = iota
+	Graphics
+	ComputeAndGraphics
+)
+
+func (t ProcessType) String() string {
+	switch t {
+	case Compute:
+		return "C"
+	case Graphics:
+		return "G"
+	}
+	return "C+G"
+}
+
 type ProcessInfo struct {
 	PID         uint
 	Name        string
 	MemoryUsed  uint64 // MiB
+	Type        ProcessType
 	CUOccupancy *uint
 }
 
@@ -127,11 +148,43 @@ type DeviceStatus struct {
 	EnergyJ     *float64 // energy counter since driver load
 }
 
-// DeviceMode reports partitioning; the reference reports display / persistence /
-// accounting modes here (nvml.go:582-604), none of which exist on a compute-only part.
+// DeviceMode keeps the reference's three members (nvml.go:52-56, 582-604) and adds what a
+// compute-only part has instead of display and persistence modes: its partitioning.
 type DeviceMode struct {
-	ComputePartition string
-	MemoryPartition  string
+	DisplayInfo      Display    // always N/A: no display engine on the part
+	Persistence      ModeState  // always N/A: the amdgpu driver stays loaded, there is no such mode
+	AccountingInfo   Accounting // the engine's per-process accounting watch on this GPU
+	ComputePartition string     // SPX, DPX, QPX, CPX
+	MemoryPartition  string     // NPS1, NPS2, ...
+}
+
+// ModeState, Display and Accounting keep the reference's shapes (nvml.go:23-50).
+type ModeState uint
+
+const (
+	Disabled ModeState = iota
+	Enabled
+	NotApplicable
+)
+
+func (m ModeState) String() string {
+	switch m {
+	case Enabled:
+		return "Enabled"
+	case Disabled:
+		return "Disabled"
+	}
+	return "N/A"
+}
+
+type Display struct {
+	Mode   ModeState
+	Active ModeState
+}
+
+type Accounting struct {
+	Mode       ModeState
+	BufferSize *uint
 }
 
 // Event is a driver notification (GPU reset, RAS error, thermal throttle ...): the
@@ -337,11 +390,37 @@ func GetXGMILink(dev1, dev2 *Device) (connected bool, links uint, err error) {
 }
 
 func (d *Device) GetDeviceMode() (*DeviceMode, error) {
-	c, m, err := deviceMode(d.Index)
+	m, err := deviceMode(d.Index)
 	if err != nil {
 		return nil, err
 	}
-	return &DeviceMode{ComputePartition: c, MemoryPartition: m}, nil
+	mode := &DeviceMode{DisplayInfo: Display{NotApplicable, NotApplicable}, Persistence: NotApplicable,
+		ComputePartition: m.compute, MemoryPartition: m.memory}
+	if m.accountingOn {
+		size := m.accountingBufferSize
+		mode.AccountingInfo = Accounting{Mode: Enabled, BufferSize: &size}
+	}
+	return mode, nil
+}
+
+// GetComputeRunningProcesses returns pids and used memory in MiB (nvml.go:570-572).
+func (d *Device) GetComputeRunningProcesses() ([]uint, []uint64, error) {
+	procs, err := d.GetAllRunningProcesses()
+	if err != nil {
+		return nil, nil, err
+	}
+	pids, mems := make([]uint, 0, len(procs)), make([]uint64, 0, len(procs))
+	for _, p := range procs {
+		if p.Type != Graphics {
+			pids, mems = append(pids, p.PID), append(mems, p.MemoryUsed)
+		}
+	}
+	return pids, mems, nil
+}
+
+// GetGraphicsRunningProcesses is always empty on a compute-only part (nvml.go:574-576).
+func (d *Device) GetGraphicsRunningProcesses() ([]uint, []uint64, error) {
+	return []uint{}, []uint64{}, nil
 }
 
 // ReadFields reads arbitrary registry fields (ids from the C header, GM_FI_*) in

@@ -113,6 +113,21 @@ func TestFakeEventsAndProcesses(t *testing.T) {
 	if err != nil || len(p) != 1 || p[0].PID != 77 || p[0].MemoryUsed != 2048 {
 		t.Fatalf("processes: %+v %v", p, err)
 	}
+	if p[0].Type != Compute || p[0].Type.String() != "C" {
+		t.Errorf("process type: %v", p[0].Type)
+	}
+	pids, mems, err := d.GetComputeRunningProcesses()
+	if err != nil || len(pids) != 1 || pids[0] != 77 || mems[0] != 2048 {
+		t.Errorf("compute processes: %v %v %v", pids, mems, err)
+	}
+	if gp, gm, err := d.GetGraphicsRunningProcesses(); err != nil || len(gp) != 0 || len(gm) != 0 {
+		t.Errorf("graphics processes on a compute-only part: %v %v %v", gp, gm, err)
+	}
+	m, err := d.GetDeviceMode()
+	if err != nil || m.ComputePartition != "SPX" || m.DisplayInfo.Mode.String() != "N/A" || m.Persistence.String() != "N/A" ||
+		m.AccountingInfo.Mode != Disabled || m.AccountingInfo.BufferSize != nil {
+		t.Errorf("device mode: %+v %v", m, err)
+	}
 }
 
 func TestInitRefcount(t *testing.T) {
