@@ -1,0 +1,9 @@
+package hostengine
+
+// Names of the reference's dcgm package for the types that carry an AMD-neutral name here,
+// so code written against it keeps compiling: DcgmStatus (bindings/go/dcgm/
+// hostengine_status.go:13-16) and XIDErrorInfo (process_info.go:46-49).
+type (
+	DcgmStatus   = Status
+	XIDErrorInfo = CriticalEvents
+)
