@@ -468,6 +468,7 @@ class AmdSmiBackend : public Backend {
         s.serial = trim(a.asic_serial);
         if (valid(a.num_of_compute_units)) s.num_cu = a.num_of_compute_units;
         if (valid(a.oam_id)) s.oam_id = (int)a.oam_id;
+        s.partition_id = (int)d.partition_id;
         if (valid(a.target_graphics_version)) s.gfx_target = strprintf("gfx%llx", (unsigned long long)a.target_graphics_version);
       }
     }

@@ -24,6 +24,7 @@ struct GpuStatic {
   int hip_id = -1;
   int drm_render_minor = -1;
   int oam_id = -1;
+  int partition_id = 0;  // index of this compute partition inside its GPU; 0 when not partitioned
   uint32_t num_xcd = 0, num_cu = 0;
   uint32_t pcie_max_gen = 0, pcie_max_width = 0;
   double power_cap_w = NAN, power_cap_default_w = NAN, power_cap_max_w = NAN;

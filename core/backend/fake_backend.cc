@@ -54,6 +54,7 @@ class FakeBackend : public Backend {
       else if (k == "unsupported_gpu") unsupported_gpu_ = atoi(v.c_str());
       else if (k == "sample_cost_us") sample_cost_us_ = atoi(v.c_str());
       else if (k == "steady") steady_ = atoi(v.c_str()) != 0;  // telemetry independent of the sample count
+      else if (k == "partition_mode") partition_mode_ = v;       // e.g. CPX: every entry is one of 8 partitions of a GPU
     }
     if (ngpus_ > GM_MAX_GPUS) ngpus_ = GM_MAX_GPUS;
   }
@@ -81,8 +82,12 @@ class FakeBackend : public Backend {
       s.gfx_target = "gfx950";
       s.device_path = strprintf("/dev/dri/renderD%d", 128 + (int)i);
       s.cpu_affinity = i < (ngpus_ + 1) / 2 ? "0-63,128-191" : "64-127,192-255";
-      s.compute_partition = "SPX";
+      s.compute_partition = partition_mode_.empty() ? "SPX" : partition_mode_;
       s.memory_partition = "NPS1";
+      if (!partition_mode_.empty() && partition_mode_ != "SPX") {
+        const uint32_t per_gpu = partition_mode_ == "DPX" ? 2 : partition_mode_ == "QPX" ? 4 : 8;
+        s.partition_id = (int)(i % per_gpu);
+      }
       s.numa_node = i < (ngpus_ + 1) / 2 ? 0 : 1;
       s.hip_id = (int)i;
       s.drm_render_minor = 128 + (int)i;
@@ -450,6 +455,7 @@ class FakeBackend : public Backend {
  private:
   uint32_t ngpus_ = 8, seed_ = 1;
   bool fail_init_ = false, events_supported_ = true, topology_unsupported_ = false, steady_ = false;
+  std::string partition_mode_;
   double default_load_ = 0;
   int unsupported_gpu_ = -1;
   int sample_cost_us_ = 0;

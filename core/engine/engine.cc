@@ -833,6 +833,7 @@ void static_value(const GpuStatic& s, uint16_t id, gm_value_t* o) {
     case GM_FI_DEV_NUM_CU: i64(s.num_cu, s.num_cu > 0); break;
     case GM_FI_DEV_HIP_ID: i64(s.hip_id, s.hip_id >= 0); break;
     case GM_FI_DEV_OAM_ID: i64(s.oam_id, s.oam_id >= 0); break;
+    case GM_FI_DEV_PARTITION_ID: i64(s.partition_id, true); break;
     case GM_FI_DEV_PCIE_MAX_GEN: i64(s.pcie_max_gen, s.pcie_max_gen > 0); break;
     case GM_FI_DEV_PCIE_MAX_WIDTH: i64(s.pcie_max_width, s.pcie_max_width > 0); break;
     case GM_FI_DEV_POWER_CAP_DEFAULT: dbl(s.power_cap_default_w); break;

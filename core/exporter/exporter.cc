@@ -128,6 +128,7 @@ gm_status_t Exporter::init() {
   }
   uuids_.clear();
   bdfs_.clear();
+  partitions_.clear();
   for (uint32_t g : gpus_) {
     gm_device_attributes_t a;
     a.version = GM_DEVICE_ATTRIBUTES_VERSION;
@@ -137,6 +138,15 @@ gm_status_t Exporter::init() {
     std::string bdf = a.pci_bdf;
     for (auto& c : bdf) c = (char)tolower((unsigned char)c);
     bdfs_.push_back(bdf);
+    // A partitioned GPU (DPX / QPX / CPX) is enumerated once per partition: the entries keep their own
+    // gpu index and uuid, and say which slice of the device they are.
+    int part = -1;
+    if (a.compute_partition[0] && strcmp(a.compute_partition, "SPX") != 0) {
+      const uint16_t fid = GM_FI_DEV_PARTITION_ID;
+      gm_value_t v;
+      if (engine_->latest_values(g, &fid, 1, &v) == GM_ST_OK && v.status == GM_VS_OK) part = (int)v.v.i64;
+    }
+    partitions_.push_back(part);
   }
   fields_.clear();
   for (auto& fam : build_families(cfg_.profiling, cfg_.amd_extras))
@@ -261,6 +271,7 @@ void Exporter::render(std::string* out) {
     base[g] = strprintf("{gpu=\"%u\",uuid=\"", gpus_[g]);
     append_escaped(&base[g], uuids_[g]);
     base[g] += "\"";
+    if (partitions_[g] >= 0) base[g] += strprintf(",partition=\"%d\"", partitions_[g]);
     const PodInfo* p = nullptr;
     auto it = pod_map_.find(uuids_[g]);
     if (it != pod_map_.end()) p = &it->second;

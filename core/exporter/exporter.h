@@ -79,6 +79,7 @@ class Exporter {
   ExporterConfig cfg_;
   std::vector<uint32_t> gpus_;
   std::vector<std::string> uuids_, bdfs_;
+  std::vector<int> partitions_;  // compute-partition index per exported entry; -1 = GPU is not partitioned (no label)
   std::vector<uint16_t> fields_;  // every field id fetched per GPU
   gm_group_t group_ = 0;
   gm_field_group_t fg_ = 0;

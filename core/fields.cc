@@ -35,6 +35,7 @@ std::vector<FieldDef> build_table() {
     {GM_FI_DEV_MEMORY_PARTITION,  STR, SRC_STATIC, "memory_partition", "", 0, 0, nullptr, nullptr, nullptr, 0},
     {GM_FI_DEV_HIP_ID,            I64, SRC_STATIC, "hip_id", "", 0, 0, nullptr, nullptr, nullptr, 0},
     {GM_FI_DEV_OAM_ID,            I64, SRC_STATIC, "oam_id", "", 0, 0, nullptr, nullptr, nullptr, 0},
+    {GM_FI_DEV_PARTITION_ID,      I64, SRC_STATIC, "partition_id", "", 0, 0, nullptr, nullptr, nullptr, 0},
     {GM_FI_DEV_PCIE_MAX_GEN,      I64, SRC_STATIC, "pcie_max_gen", "", 0, 0, nullptr, nullptr, nullptr, 0},
     {GM_FI_DEV_PCIE_MAX_WIDTH,    I64, SRC_STATIC, "pcie_max_width", "", 0, 0, nullptr, nullptr, nullptr, 0},
     {GM_FI_DEV_POWER_CAP_DEFAULT, DBL, SRC_STATIC, "power_cap_default", "W", 0, 0, nullptr, nullptr, nullptr, 0},

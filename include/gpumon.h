@@ -121,6 +121,7 @@ enum {
   GM_FI_DEV_MEMORY_PARTITION = 65,  /* NPS1/NPS2/... */
   GM_FI_DEV_HIP_ID = 66,
   GM_FI_DEV_OAM_ID = 67,
+  GM_FI_DEV_PARTITION_ID = 68,      /* index of this compute partition inside its GPU (0 when not partitioned) */
   GM_FI_DEV_PCIE_MAX_GEN = 235,
   GM_FI_DEV_PCIE_MAX_WIDTH = 236,
   GM_FI_DEV_PCIE_GEN = 237,

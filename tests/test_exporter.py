@@ -210,6 +210,32 @@ def test_last_not_idle_latch_survives_a_restart(engine2, tmp_path):
     assert sorted(p.name for p in state.parent.iterdir()) == ["exporter.json"]
 
 
+def test_partitioned_gpus_carry_a_partition_label():
+    """In DPX / QPX / CPX mode the device library enumerates one entry per compute partition; each keeps
+    its own gpu index and uuid and is told apart by an extra label.  Unpartitioned (SPX) nodes - every
+    other test in this file - have no such label, so the reference's label set is unchanged there."""
+    E.init(backend="fake", backend_spec="gpus=16,seed=3,steady=1,partition_mode=CPX")
+    try:
+        assert E.latest_values(9, [68])[68] == 1  # GM_FI_DEV_PARTITION_ID: entry 9 is slice 1 of the second GPU
+        assert E.device_attributes(9)["compute_partition"] == "CPX"
+        with E.Exporter() as ex:
+            ex.sweep()
+            fams = parse(ex.render())
+            rows = [l for l, _ in fams["dcgm_sm_clock"].samples]
+            assert [list(l) for l in rows][0] == ["gpu", "uuid", "partition"]  # after the reference's two labels
+            assert [l["partition"] for l in rows] == [str(i % 8) for i in range(16)]
+            assert len({l["uuid"] for l in rows}) == 16
+    finally:
+        E.shutdown()
+    E.init(backend="fake", backend_spec="gpus=2,seed=3,steady=1")
+    try:
+        with E.Exporter() as ex:
+            ex.sweep()
+            assert "partition=" not in ex.render()
+    finally:
+        E.shutdown()
+
+
 def test_gpu_subset_and_bad_subset(engine):
     with E.Exporter(interval_ms=1000, gpus="5,2") as ex:
         ex.sweep()
