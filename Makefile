@@ -39,7 +39,7 @@ $(BUILD)/obj/%.o: %.cc
 $(BUILD)/libgpumon.so: $(CORE_OBJ)
 	$(CXX) -shared -o $@ $^ $(LDFLAGS)
 
-$(BUILD)/bin/%: cmd/%.cc $(BUILD)/libgpumon.so
+$(BUILD)/bin/%: cmd/%.cc cmd/cli_common.h include/gpumon.h $(BUILD)/libgpumon.so
 	@mkdir -p $(dir $@)
 	$(CXX) $(CXXFLAGS) -fvisibility=default -o $@ $< -L$(BUILD) -lgpumon -Wl,-rpath,'$$ORIGIN/..' $(LDFLAGS)
 

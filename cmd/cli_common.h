@@ -32,8 +32,68 @@ static inline void install_signals() {
   signal(SIGPIPE, SIG_IGN);
 }
 
+// One configuration for flags, environment and file.  `--config FILE` is replaced, in place, by the flags
+// written in FILE (whitespace-separated words, one or more per line; `#` starts a comment; a word may be
+// quoted with "..."), and the words of $GPUMON_ARGS are put in front of the command line, so a flag given
+// on the command line wins over the file, which wins over the environment.  Returns false when a file
+// cannot be read.  The reference has only flags and compile-time constants (watchers.go:15-21).
+static inline bool split_words(const std::string& text, std::vector<std::string>* out) {
+  std::string cur;
+  bool in_word = false, quoted = false;
+  for (size_t i = 0; i <= text.size(); i++) {
+    const char ch = i < text.size() ? text[i] : '\n';
+    if (quoted) {
+      if (ch == '"') quoted = false;
+      else cur += ch;
+      continue;
+    }
+    if (ch == '#') {  // comment until the end of the line
+      while (i < text.size() && text[i] != '\n') i++;
+    }
+    if (ch == '"') { quoted = in_word = true; continue; }
+    if (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r' || ch == '#') {
+      if (in_word) out->push_back(cur);
+      cur.clear();
+      in_word = false;
+      continue;
+    }
+    cur += ch;
+    in_word = true;
+  }
+  return !quoted;
+}
+
+static inline bool expand_config(std::vector<std::string>& args) {
+  std::vector<std::string> out;
+  if (const char* env = getenv("GPUMON_ARGS")) split_words(env, &out);
+  for (size_t i = 0; i < args.size(); i++) {
+    if (args[i] != "--config") {
+      out.push_back(args[i]);
+      continue;
+    }
+    if (i + 1 >= args.size()) return false;
+    FILE* f = fopen(args[++i].c_str(), "r");
+    if (!f) {
+      fprintf(stderr, "cannot read config file %s\n", args[i].c_str());
+      return false;
+    }
+    std::string text;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    fclose(f);
+    if (!split_words(text, &out)) {
+      fprintf(stderr, "unterminated quote in %s\n", args[i].c_str());
+      return false;
+    }
+  }
+  args.swap(out);
+  return true;
+}
+
 // Consumes the connection flags out of args; returns false on a missing value.
 static inline bool parse_conn(std::vector<std::string>& args, CliConn* c) {
+  if (!expand_config(args)) return false;
   std::vector<std::string> rest;
   for (size_t i = 0; i < args.size(); i++) {
     const std::string& a = args[i];

@@ -10,6 +10,7 @@
 
 int main(int argc, char** argv) {
   std::vector<std::string> args(argv + 1, argv + argc);
+  if (!expand_config(args)) return 2;  // --config FILE, $GPUMON_ARGS
   std::string src, dst, sock, res, prefix, listen = ":9400";
   int timeout = 0, liveness = 0, refresh = 0, verbosity = -1;
   for (size_t i = 0; i < args.size(); i++) {

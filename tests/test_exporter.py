@@ -330,6 +330,26 @@ def test_exporter_binary_flags(tmp_path):
     assert "GPUs:1,3" in r.stderr
 
 
+def test_flags_from_config_file_and_environment(tmp_path):
+    """One configuration: $GPUMON_ARGS < --config FILE < command line (later words win)."""
+    exe = bin_path("gpumon-exporter")
+    out_file, out_cli = tmp_path / "from_file.prom", tmp_path / "from_cli.prom"
+    cfg = tmp_path / "exporter.conf"
+    cfg.write_text(f'# node exporter settings\n-e --once   # embedded, one sweep\n-o "{out_file}"\n--gpus 1\n')
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=4,steady=1", GPUMON_ARGS="-p --gpus 0,2")
+    r = subprocess.run([exe, "--config", str(cfg)], env=env, capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0, r.stderr
+    fams = parse(out_file.read_text())
+    assert [l["gpu"] for l, _ in fams["dcgm_sm_clock"].samples] == ["1"]  # the file overrides the environment
+    assert "dcgm_fi_prof_gr_engine_active" in fams  # -p came from the environment
+    r = subprocess.run([exe, "--config", str(cfg), "-o", str(out_cli), "--gpus", "3"], env=env, capture_output=True, text=True,
+                       timeout=30)
+    assert r.returncode == 0, r.stderr
+    assert [l["gpu"] for l, _ in parse(out_cli.read_text())["dcgm_sm_clock"].samples] == ["3"]  # the command line overrides both
+    r = subprocess.run([exe, "--config", str(tmp_path / "missing.conf")], env=env, capture_output=True, text=True, timeout=30)
+    assert r.returncode != 0 and "cannot read config file" in r.stderr
+
+
 def test_interval_floor_is_clamped_in_library(engine2):
     with E.Exporter(interval_ms=5) as ex:  # library clamps instead of failing
         ex.sweep()
