@@ -119,15 +119,39 @@ static void test_concurrent_engine() {
     c.version = GM_EXPORTER_CONFIG_VERSION;
     c.interval_ms = 100;
     c.profiling = c.amd_extras = c.self_metrics = 1;
+    // a diagnostics report that is rewritten while it is being exported, and a state file
+    char report[64], state[64];
+    snprintf(report, sizeof report, "/tmp/gpumon-test-%d-diag.json", (int)getpid());
+    snprintf(state, sizeof state, "/tmp/gpumon-test-%d-state.json", (int)getpid());
+    auto write_report = [&](int errors) {
+      std::string tmp = std::string(report) + ".tmp";
+      FILE* f = fopen(tmp.c_str(), "w");
+      CHECK(f);
+      fprintf(f, "{\"gpu\":3,\"timestamp\":1700000000,\"memtest\":{\"bytes_tested\":1024,\"errors\":%d},\"result\":\"%s\"}\n", errors,
+              errors ? "fail" : "pass");
+      fclose(f);
+      CHECK(rename(tmp.c_str(), report) == 0);
+    };
+    write_report(0);
+    c.diag_results_path = report;
+    c.state_path = state;
     gm_exporter_t ex;
     OK(gm_exporter_create(&c, &ex));
     std::vector<char> buf(1 << 20);
+    int round = 0;
     while (!stop) {
       size_t len = buf.size();
       OK(gm_exporter_render(ex, buf.data(), &len));
       CHECK(len > 1000 && strstr(buf.data(), "# TYPE dcgm_gpu_temp gauge"));  // single GPUs may be blanked by the injector
+      CHECK(strstr(buf.data(), "gpumon_diag_memtest_errors{gpu=\"3\"}"));
+      if (++round % 50 == 0) write_report(round % 100 == 0);
     }
-    OK(gm_exporter_destroy(ex));
+    OK(gm_exporter_destroy(ex));  // writes the state file
+    FILE* f = fopen(state, "r");
+    CHECK(f);
+    if (f) fclose(f);
+    unlink(report);
+    unlink(state);
   });
   th.emplace_back([&] {  // fault injector
     std::mt19937 rng(7);
