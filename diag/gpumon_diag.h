@@ -166,6 +166,7 @@ GMD_API int gmd_gemm_set_variant(int variant);
  * 100 MHz real-time ticks) of the last launch of a stamped variant.  GMD_ERR_UNSUPPORTED in
  * the product library. */
 GMD_API int gmd_gemm_read_stamps(unsigned long long* out, int n_pairs);
+GMD_API int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles);
 
 /* ---------------------------------------------------------- interconnect -- */
 /* Single-process RCCL sweep: one communicator per listed GPU (ncclCommInitAll),

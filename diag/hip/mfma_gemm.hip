@@ -278,12 +278,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 // real-time ticks spent in the kernel (ABL bit 4).  Nothing else reads this buffer.
 constexpr int kStampSlots = 4096;
 __device__ unsigned long long g_gemm_stamps[2 * kStampSlots];
+// Persistent grid with stamps: per tile, 100 MHz real-time ticks at the top of the tile loop, after the wait
+// for the first half-tiles (and the previous tile's stores), after the last MFMA, and the shader ticks of the K loop.
+__device__ unsigned long long g_gemm_timeline[4 * kStampSlots];
 #endif
 
 // ABL is for timing-only ablation builds (make diag-ablate; results are wrong by design):
 // bit 0 drops the fragment reads of the loop, bit 1 the LDS-DMA and its waits, bit 2 the MFMAs;
 // bit 3 points every workgroup at the operands of tile (0, 0) (an always-L2-resident stream).
-template <int DT, int ABL = 0, int AHEAD = kAheadDefault>
+template <int DT, int ABL = 0, int AHEAD = kAheadDefault, bool PERSIST = false>
 __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
   constexpr int kAhead = AHEAD;  // half-tiles issued ahead of the running phase; kAhead - 2 of them are in flight
@@ -292,11 +295,20 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int nwg = gridDim.x;
-  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8n = nwg & 7;
-  const int wgid = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (blockIdx.x >> 3);
+  // Tiles are dealt to the XCDs in contiguous chunks (bijective for any count).  One workgroup per tile, or
+  // (PERSIST) a grid of one workgroup per CU in which workgroup j of an XCD walks tiles j, j + G/8, ... of the
+  // XCD's chunk: the XCD still works on G/8 neighbouring tiles at any time, and a workgroup fetches the first
+  // half-tiles of its next tile before it stores the finished one.
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  const int total = PERSIST ? tiles_m * tiles_n : (int)gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = total >> 3, r8n = total & 7;
+  const int chunk0 = xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8;
+  const int chunk_end = chunk0 + q8 + (xcd < r8n ? 1 : 0);
+  const int tile_step = PERSIST ? max((int)gridDim.x >> 3, 1) : total;
+  int wgid = chunk0 + (int)(blockIdx.x >> 3);
+  if (wgid >= chunk_end) return;  // whole workgroup, before any barrier
   int tm, tn;
-  tile_of(wgid, M / BM, N / BN, &tm, &tn);
+  tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
 #ifdef GMD_GEMM_ABLATE
   unsigned long long stamp_t0 = 0, stamp_r0 = 0;
   if constexpr (ABL & 16) {
@@ -363,10 +375,6 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
   };
 
   f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   i32x8 a[4], bp[2], bq[2];
   if constexpr (ABL & 1) {  // the loop never loads them: give them defined contents
 #pragma unroll
@@ -379,20 +387,17 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
 
-  // Prologue: half-tiles 0..kAhead-1 in flight (all of K-tile 0 and the start of K-tile 1), 0 and 1 landed.
+  // Prologue of a tile: half-tiles 0..kAhead-1 in flight (all of K-tile 0 and the start of K-tile 1).
   static_assert(kAhead >= 5 && kAhead <= 7, "ring of 8 slots: 2 phases of read-to-overwrite margin need kAhead <= 7");
-  issue(I0{}, I0{}, 0);
-  issue(I1{}, I0{}, 0);
-  issue(I2{}, I0{}, 0);
-  issue(I3{}, I0{}, 0);
-  issue(I0{}, I1{}, 1);
-  if constexpr (kAhead > 5) issue(I1{}, I1{}, 1);
-  if constexpr (kAhead > 6) issue(I2{}, I1{}, 1);
-  wait_vmcnt<2 * (kAhead - 2)>();
-  GMD_PHASE_FENCE();
-  read_b(bp, 0);  // B-lo of K-tile 0
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (wr == 1) { GMD_PHASE_FENCE(); }  // run the second wave row one barrier behind the first
+  auto issue_prologue = [&]() {
+    issue(I0{}, I0{}, 0);
+    issue(I1{}, I0{}, 0);
+    issue(I2{}, I0{}, 0);
+    issue(I3{}, I0{}, 0);
+    issue(I0{}, I1{}, 1);
+    if constexpr (kAhead > 5) issue(I1{}, I1{}, 1);
+    if constexpr (kAhead > 6) issue(I2{}, I1{}, 1);
+  };
 
   // One phase.  P: phase within a pair of K-tiles (0..7).  TAIL: last pair, where issue stops and the waits shrink.
   auto phase = [&](auto PH, auto TAILF, int kt0) {
@@ -436,49 +441,97 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
   const int npairs = (int)(row_bytes / BKB) >> 1;
   using F = std::integral_constant<int, 0>;
   using T = std::integral_constant<int, 1>;
-  for (int it = 0; it + 1 < npairs; it++) {
-    const int kt0 = 2 * it;
-    phase(std::integral_constant<int, 0>{}, F{}, kt0);
-    phase(std::integral_constant<int, 1>{}, F{}, kt0);
-    phase(std::integral_constant<int, 2>{}, F{}, kt0);
-    phase(std::integral_constant<int, 3>{}, F{}, kt0);
-    phase(std::integral_constant<int, 4>{}, F{}, kt0);
-    phase(std::integral_constant<int, 5>{}, F{}, kt0);
-    phase(std::integral_constant<int, 6>{}, F{}, kt0);
-    phase(std::integral_constant<int, 7>{}, F{}, kt0);
-  }
-  {
-    const int kt0 = 2 * (npairs - 1);
-    phase(std::integral_constant<int, 0>{}, T{}, kt0);
-    phase(std::integral_constant<int, 1>{}, T{}, kt0);
-    phase(std::integral_constant<int, 2>{}, T{}, kt0);
-    phase(std::integral_constant<int, 3>{}, T{}, kt0);
-    phase(std::integral_constant<int, 4>{}, T{}, kt0);
-    phase(std::integral_constant<int, 5>{}, T{}, kt0);
-    phase(std::integral_constant<int, 6>{}, T{}, kt0);
-    phase(std::integral_constant<int, 7>{}, T{}, kt0);
-  }
-  if (wr == 0) { GMD_PHASE_FENCE(); }  // the barrier the second wave row took up front
+
+  issue_prologue();
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Half-tiles 0 and 1 landed.  A persistent workgroup has the previous tile's stores in the same counter
+    // behind the prologue's loads, and loads and stores complete in no fixed order with each other: wait for all.
 #ifdef GMD_GEMM_ABLATE
-  if constexpr (ABL & 16) {
-    asm volatile("s_nop 0" ::"v"(acc[7][3]));  // stamp behind the last MFMA's result
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && wgid < kStampSlots) {
-      g_gemm_stamps[2 * wgid] = t1 - stamp_t0;
-      g_gemm_stamps[2 * wgid + 1] = r1 - stamp_r0;
+    unsigned long long tl_top = 0, tl_ready = 0, tl_t0 = 0;
+    if constexpr (PERSIST && (ABL & 16)) tl_top = __builtin_amdgcn_s_memrealtime();
+#endif
+    if constexpr (PERSIST) wait_vmcnt<0>();
+    else wait_vmcnt<2 * (kAhead - 2)>();
+    GMD_PHASE_FENCE();
+    read_b(bp, 0);  // B-lo of K-tile 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef GMD_GEMM_ABLATE
+    if constexpr (PERSIST && (ABL & 16)) {
+      tl_ready = __builtin_amdgcn_s_memrealtime();
+      tl_t0 = __builtin_amdgcn_s_memtime();
     }
-  }
+#endif
+    if (wr == 1) { GMD_PHASE_FENCE(); }  // run the second wave row one barrier behind the first
+
+    for (int it = 0; it + 1 < npairs; it++) {
+      const int kt0 = 2 * it;
+      phase(std::integral_constant<int, 0>{}, F{}, kt0);
+      phase(std::integral_constant<int, 1>{}, F{}, kt0);
+      phase(std::integral_constant<int, 2>{}, F{}, kt0);
+      phase(std::integral_constant<int, 3>{}, F{}, kt0);
+      phase(std::integral_constant<int, 4>{}, F{}, kt0);
+      phase(std::integral_constant<int, 5>{}, F{}, kt0);
+      phase(std::integral_constant<int, 6>{}, F{}, kt0);
+      phase(std::integral_constant<int, 7>{}, F{}, kt0);
+    }
+    {
+      const int kt0 = 2 * (npairs - 1);
+      phase(std::integral_constant<int, 0>{}, T{}, kt0);
+      phase(std::integral_constant<int, 1>{}, T{}, kt0);
+      phase(std::integral_constant<int, 2>{}, T{}, kt0);
+      phase(std::integral_constant<int, 3>{}, T{}, kt0);
+      phase(std::integral_constant<int, 4>{}, T{}, kt0);
+      phase(std::integral_constant<int, 5>{}, T{}, kt0);
+      phase(std::integral_constant<int, 6>{}, T{}, kt0);
+      phase(std::integral_constant<int, 7>{}, T{}, kt0);
+    }
+    if (wr == 0) { GMD_PHASE_FENCE(); }  // the barrier the second wave row took up front
+#ifdef GMD_GEMM_ABLATE
+    if constexpr (ABL & 16) {
+      asm volatile("s_nop 0" ::"v"(acc[7][3]));  // stamp behind the last MFMA's result
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+      if (threadIdx.x == 0 && wgid < kStampSlots) {
+        g_gemm_stamps[2 * wgid] = t1 - stamp_t0;
+        g_gemm_stamps[2 * wgid + 1] = r1 - stamp_r0;
+      }
+      stamp_t0 = t1;
+      stamp_r0 = r1;
+      if constexpr (PERSIST) {
+        if (threadIdx.x == 0 && wgid < kStampSlots) {
+          g_gemm_timeline[4 * wgid] = tl_top;
+          g_gemm_timeline[4 * wgid + 1] = tl_ready;
+          g_gemm_timeline[4 * wgid + 2] = r1;
+          g_gemm_timeline[4 * wgid + 3] = t1 - tl_t0;
+        }
+      }
+    }
 #endif
 
-  const int m0 = tm * BM + wr * 128 + fr;
-  const int n0 = tn * BN + wc * 64 + fq * 4;
-#pragma unroll
-  for (int mb = 0; mb < 8; mb++)
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) {
-      bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
-      *(bf16x4*)(C + (size_t)(m0 + mb * 16) * N + n0 + nb * 16) = o;
+    // Every wave is past the barrier behind the tile's last LDS read: the ring is free.  Start the next tile's
+    // fetches, then store this one while they fly.
+    const int m0 = tm * BM + wr * 128 + fr;
+    const int n0 = tn * BN + wc * 64 + fq * 4;
+    wgid += tile_step;
+    const bool more = wgid < chunk_end;
+    if (more) {
+      tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
+      gA = A + (size_t)((ABL & 8) ? 0 : tm) * BM * row_bytes;
+      gB = B + (size_t)((ABL & 8) ? 0 : tn) * BN * row_bytes;
+      issue_prologue();
     }
+#pragma unroll
+    for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+      for (int nb = 0; nb < 4; nb++) {
+        bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
+        *(bf16x4*)(C + (size_t)(m0 + mb * 16) * N + n0 + nb * 16) = o;
+      }
+    if (!more) break;
+  }
 }
 
 // ---- (2c) four waves, 128 x 128 of C each ---------------------------------------
@@ -836,9 +889,10 @@ double peak_flops_per_mfma(int dt) {
   }
 }
 
-// Which GEMM schedule runs: -1 = the faster pipeline for the dtype (default), 2 = four waves of
-// 128 x 128, 1 = eight waves of 128 x 64, 0 = the simple double-buffered loop (kept as the A/B
-// baseline and for odd K-tile counts).
+// Which GEMM schedule runs: -1 = the faster pipeline for the dtype (default), 3 = eight waves of
+// 128 x 64 as a persistent grid (one workgroup per CU walking its tiles), 2 = four waves of
+// 128 x 128, 1 = eight waves of 128 x 64 with one workgroup per tile, 0 = the simple
+// double-buffered loop (kept as the A/B baseline and for odd K-tile counts).
 constexpr int kVariantUnset = -2;
 int g_gemm_variant = kVariantUnset;
 
@@ -848,6 +902,20 @@ int gemm_variant() {
     g_gemm_variant = e && *e ? atoi(e) : -1;
   }
   return g_gemm_variant;
+}
+
+// Workgroups of the persistent schedule: one per CU of the current device (128 KiB of LDS each, so the
+// dispatcher cannot place two on a CU), a multiple of 8 so every XCD gets the same number.
+int persistent_grid() {
+  static int grid = 0;
+  if (!grid) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 8)
+      cus = gmd::kCUs;
+    grid = cus & ~7;
+  }
+  return grid;
 }
 
 template <int DT>
@@ -933,6 +1001,18 @@ int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t ro
       GMD_HIP(hipGetLastError());
       return GMD_OK;
     }
+    case 53: {  // the persistent eight-wave kernel with clock stamps and the per-tile timeline
+      static bool once = false;
+      if (!once) {
+        GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, 16, kAheadDefault, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        once = true;
+      }
+      gemm_pp_kernel<DT, 16, kAheadDefault, true><<<persistent_grid(), kThreads, kLdsBytes, st>>>(
+          (const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+      GMD_HIP(hipGetLastError());
+      return GMD_OK;
+    }
     default: break;
   }
 #endif
@@ -945,6 +1025,15 @@ int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t ro
       w4_attr = true;
     }
     gemm_w4_kernel<DT><<<grid, kThreadsW4, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+  } else if (variant == 3 && ktiles >= 2 && (ktiles & 1) == 0 && grid > persistent_grid()) {
+    static bool ps_attr = false;
+    if (!ps_attr) {
+      GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, 0, kAheadDefault, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+      ps_attr = true;
+    }
+    gemm_pp_kernel<DT, 0, kAheadDefault, true><<<persistent_grid(), kThreads, kLdsBytes, st>>>(
+        (const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
   } else if (variant >= 1 && ktiles >= 2 && (ktiles & 1) == 0)
     gemm_pp_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
   else
@@ -960,12 +1049,12 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46) || variant == 51) {
+      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53) {
     g_gemm_variant = variant;
     return GMD_OK;
   }
 #endif
-  if (variant < -1 || variant > 2) return GMD_ERR_BADPARAM;
+  if (variant < -1 || variant > 3) return GMD_ERR_BADPARAM;
   g_gemm_variant = variant;
   return GMD_OK;
 }
@@ -979,6 +1068,19 @@ int gmd_gemm_read_stamps(unsigned long long* out, int n_pairs) {
 #else
   (void)out;
   (void)n_pairs;
+  return GMD_ERR_UNSUPPORTED;
+#endif
+}
+
+// Ablation builds only: per-tile timeline of the last stamped persistent launch (variant 53), four values a tile.
+int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles) {
+#ifdef GMD_GEMM_ABLATE
+  if (!out || n_tiles <= 0 || n_tiles > kStampSlots) return GMD_ERR_BADPARAM;
+  GMD_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_timeline), sizeof(unsigned long long) * 4 * n_tiles));
+  return GMD_OK;
+#else
+  (void)out;
+  (void)n_tiles;
   return GMD_ERR_UNSUPPORTED;
 #endif
 }

@@ -188,7 +188,8 @@ def gemm_stress(dtype="bf16", m=8192, n=8192, k=8192, seconds=2.0, verify=True, 
 
 def gemm_set_variant(variant):
     """-1 = fastest pipeline per dtype (default), 1 = eight waves x 128x64, 2 = four waves x 128x128
-    (accumulators in AGPRs), 0 = simple double-buffered loop (A/B baseline)."""
+    (accumulators in AGPRs), 3 = eight waves x 128x64 as a persistent grid (one workgroup per CU),
+    0 = simple double-buffered loop (A/B baseline)."""
     rc = _lib().gmd_gemm_set_variant(int(variant))
     if rc:
         raise DiagError(rc, "gmd_gemm_set_variant")

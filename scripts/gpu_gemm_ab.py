@@ -1,5 +1,5 @@
-"""A/B of the three GEMM schedules on random data: numerics against fp32 matmul, then
-interleaved timing (variants 0 / 1 / 2 alternate inside one process) at several shapes,
+"""A/B of the GEMM schedules on random data: numerics against fp32 matmul, then
+interleaved timing (variants 0 / 1 / 2 / 3 alternate inside one process) at several shapes,
 next to torch.matmul (hipBLASLt) for bf16.  Writes gpurun_out/gemm_ab.json."""
 import json
 import os
@@ -14,6 +14,7 @@ from k8s_gpu_monitor_amd.ops import diag  # noqa: E402
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 out = {"numerics": [], "timing": []}
+VARIANTS = (0, 1, 2, 3)
 
 
 def inputs(m, n, k, dtype, seed=0):
@@ -27,11 +28,12 @@ def inputs(m, n, k, dtype, seed=0):
 
 ok_all = True
 for dtype in ("bf16", "mxfp8"):
-    for (m, n, k) in [(256, 256, 256), (512, 768, 1024), (1024, 256, 4096), (2048, 2048, 2048), (256, 512, 128 * 3 if dtype == "mxfp8" else 64 * 6)]:
+    for (m, n, k) in [(256, 256, 256), (512, 768, 1024), (1024, 256, 4096), (2048, 2048, 2048), (256, 512, 128 * 3 if dtype == "mxfp8" else 64 * 6),
+                      (4352, 4352, 512), (8192, 4096, 256), (2304, 8192, 1280)]:  # > 256 tiles: the persistent grid loops
         a, b = inputs(m, n, k, dtype, seed=m + n + k)
         ref = a.float() @ b.float().t()
         res = {}
-        for v in (0, 1, 2):
+        for v in VARIANTS:
             diag.gemm_set_variant(v)
             c = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=dev)
             for _ in range(3):  # repeated: a race would show as run-to-run differences
@@ -42,21 +44,24 @@ for dtype in ("bf16", "mxfp8"):
             ok = bool(torch.isfinite(c.float()).all()) and err < 6e-3
             ok_all &= ok
             out["numerics"].append({"dtype": dtype, "shape": [m, n, k], "variant": v, "rel_err": err, "ok": ok})
-        same = bool(torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]))
+        same = all(bool(torch.equal(res[0], res[v])) for v in VARIANTS)
+        ok_all &= same
         out["numerics"].append({"dtype": dtype, "shape": [m, n, k], "variants_bit_identical": same})
-        print(dtype, (m, n, k), "err", [round(x["rel_err"], 5) for x in out["numerics"][-4:-1]], "identical", same, flush=True)
+        print(dtype, (m, n, k), "err", [round(x["rel_err"], 5) for x in out["numerics"][-1 - len(VARIANTS):-1]], "identical", same,
+              flush=True)
 
 # race screen: many launches of the pipeline variant must give one bit pattern
-for rv, dtype in [(v, d) for v in (1, 2) for d in ("bf16", "mxfp8")]:
+for rv, dtype in [(v, d) for v in (1, 2, 3) for d in ("bf16", "mxfp8")]:
     diag.gemm_set_variant(rv)
-    a, b = inputs(4096, 4096, 4096, dtype, seed=5)
-    c = torch.empty(4096, 4096, dtype=torch.bfloat16, device=dev)
-    diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), 4096, 4096, 4096, stream)
+    S = 8192 if rv == 3 else 4096  # the persistent grid needs more tiles than CUs
+    a, b = inputs(S, S, 4096, dtype, seed=5)
+    c = torch.empty(S, S, dtype=torch.bfloat16, device=dev)
+    diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), S, S, 4096, stream)
     torch.cuda.synchronize()
     first = c.clone()
     bad = 0
     for i in range(200):
-        diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), 4096, 4096, 4096, stream)
+        diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), S, S, 4096, stream)
         if i % 20 == 19:
             torch.cuda.synchronize()
             bad += int(not torch.equal(c, first))
@@ -84,10 +89,10 @@ for dtype in ("bf16", "mxfp8"):
         a, b = inputs(s, s, s, dtype, seed=s)
         c = torch.empty(s, s, dtype=torch.bfloat16, device=dev)
         flops = 2.0 * s ** 3
-        best = {0: 1e9, 1: 1e9, 2: 1e9, "torch": 1e9}
+        best = {v: 1e9 for v in VARIANTS + ("torch",)}
         n = 20 if s <= 8192 else 5
         for rep in range(4):  # interleaved A/B
-            for v in (0, 1, 2):
+            for v in VARIANTS:
                 diag.gemm_set_variant(v)
                 ms = timeit(lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), s, s, s, stream), n)
                 best[v] = min(best[v], ms)
@@ -95,13 +100,14 @@ for dtype in ("bf16", "mxfp8"):
                 bt = b.t()
                 ms = timeit(lambda: torch.matmul(a, bt), n)
                 best["torch"] = min(best["torch"], ms)
-        row = {"dtype": dtype, "size": s, "tflops_v0": flops / best[0] / 1e9, "tflops_v1": flops / best[1] / 1e9, "tflops_v2": flops / best[2] / 1e9}
+        row = {"dtype": dtype, "size": s}
+        row.update({f"tflops_v{v}": flops / best[v] / 1e9 for v in VARIANTS})
         if dtype == "bf16":
             row["tflops_torch"] = flops / best["torch"] / 1e9
         out["timing"].append(row)
         print(row, flush=True)
         del a, b, c
-diag.gemm_set_variant(1)
+diag.gemm_set_variant(-1)
 out["ok"] = ok_all
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/gemm_ab.json", "w"), indent=1)

@@ -189,22 +189,23 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
     the surplus issue of the last pair; an odd number of K-tiles takes the fallback path."""
     kt = 128 if dtype == "mxfp8" else 64  # elements per 128-byte K-tile
     try:
-        for (m, n, k) in [(512, 512, 2 * kt), (256, 512, 4 * kt), (512, 512, 32 * kt), (1024, 768, 128 * kt), (256, 256, 3 * kt)]:
+        for (m, n, k) in [(512, 512, 2 * kt), (256, 512, 4 * kt), (512, 512, 32 * kt), (1024, 768, 128 * kt), (256, 256, 3 * kt),
+                          (4352, 4352, 4 * kt)]:  # 289 tiles: more than CUs, so variant 3 runs as a persistent grid
             a, b = _gemm_inputs(dev, m, n, k, dtype, seed=k)
             outs = {}
-            for variant in (0, 1, 2, -1):
+            for variant in (0, 1, 2, 3, -1):
                 diag.gemm_set_variant(variant)
                 c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
                 diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, _stream())
                 torch.cuda.synchronize()
                 outs[variant] = c
-                if variant in (1, 2):
+                if variant in (1, 2, 3):
                     c2 = torch.empty_like(c)
                     for _ in range(20):
                         diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c2.data_ptr(), m, n, k, _stream())
                     torch.cuda.synchronize()
                     assert torch.equal(c2, c), (variant, m, n, k)
-            for variant in (1, 2, -1):
+            for variant in (1, 2, 3, -1):
                 assert torch.equal(outs[0], outs[variant]), (variant, m, n, k)
         with pytest.raises(diag.DiagError):
             diag.gemm_set_variant(9)
