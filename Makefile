@@ -1,6 +1,7 @@
 # Build of the MI355X-native GPU monitoring stack.
 #   make            -> build/libgpumon.so, build/bin/{gpumon,gpumon-exporter,gpumon-hostengine,gpumon-pod-exporter}
 #   make diag       -> build/libgpumon_diag.so (HIP kernels, --offload-arch=gfx950) + build/bin/gpumon-diag
+#   make prof       -> build/libgpumon_prof.so (device-wide CU / MFMA counters, optional) + build/bin/gpumon-prof-probe
 #   make tsan|asan  -> sanitizer builds of the core + C++ tests (CPU, fake backend)
 #   make test       -> C++ unit tests
 ROCM      ?= /opt/rocm
@@ -27,7 +28,7 @@ DIAG_HIP := diag/hip/hbm_stream.hip diag/hip/memtest.hip diag/hip/mfma_gemm.hip 
 DIAG_OBJ := $(DIAG_HIP:%.hip=$(BUILD)/obj/%.o)
 HIPFLAGS += --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Idiag -Wno-unused-result
 
-.PHONY: all core bins diag test tsan asan clean
+.PHONY: all core bins diag prof test tsan asan clean
 all: core bins
 core: $(BUILD)/libgpumon.so
 bins: $(BINS:%=$(BUILD)/bin/%)
@@ -56,6 +57,16 @@ $(BUILD)/bin/gpumon-diag: cmd/gpumon-diag.cc cmd/cli_common.h diag/gpumon_diag.h
 	@mkdir -p $(dir $@)
 	$(CXX) $(CXXFLAGS) -fvisibility=default -o $@ $< -L$(BUILD) -lgpumon_diag -lgpumon \
 	    -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath-link,$(ROCM)/lib $(LDFLAGS)
+
+# ---- optional profiling-counter plugin (rocprofiler-sdk device counting + HSA) -----
+# Loaded by libgpumon.so with dlopen when GPUMON_PROF_COUNTERS=1; nothing links against it.
+prof: $(BUILD)/libgpumon_prof.so $(BUILD)/bin/gpumon-prof-probe
+$(BUILD)/libgpumon_prof.so: core/prof/prof_counters.cc core/prof/prof_counters.h
+	@mkdir -p $(BUILD)
+	$(CXX) $(CXXFLAGS) -D__HIP_PLATFORM_AMD__ -Wno-deprecated-declarations -shared -o $@ $< -L$(ROCM)/lib -lrocprofiler-sdk -lhsa-runtime64 -Wl,-rpath,$(ROCM)/lib $(LDFLAGS)
+$(BUILD)/bin/gpumon-prof-probe: cmd/gpumon-prof-probe.cc core/prof/prof_counters.h
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS) -o $@ $< $(LDFLAGS)
 
 # Timing-only ablation builds of the GEMM pipeline (fragment reads / DMA / MFMAs
 # removed one at a time); used by scripts/gpu_gemm_ablate.py, never by the product.

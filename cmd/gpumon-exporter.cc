@@ -5,6 +5,9 @@
 //
 //   -e               run the host engine inside this process (embedded)
 //   -p               also export the five profiling metrics
+//   --prof-counters  with -e: feed dcgm_fi_prof_pipe_tensor_active from the MFMA pipe's hardware counter
+//                    (loads libgpumon_prof.so: rocprofiler-sdk device counting + HSA inside this process;
+//                    same as GPUMON_PROF_COUNTERS=1; implies -p)
 //   -o FILE          publish atomically to FILE (default /run/prometheus/dcgm.prom; "" disables)
 //   -d MS            collection interval, >= 100 (default 1000)
 //   --listen ADDR    serve /metrics, /gpu/metrics, /healthz (e.g. :9400)
@@ -65,6 +68,7 @@ int main(int argc, char** argv) {
     if (a == "-h" || a == "--help") { usage(argv[0]); return 1; }
     else if (a == "-e") embedded = true;
     else if (a == "-p") profiling = true;
+    else if (a == "--prof-counters") { profiling = true; setenv("GPUMON_PROF_COUNTERS", "1", 1); }
     else if (a == "-o") val(&out);
     else if (a == "-d") { val(&tmp); interval = atol(tmp.c_str()); }
     else if (a == "--listen") val(&listen);

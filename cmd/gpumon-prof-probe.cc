@@ -1,0 +1,82 @@
+// gpumon-prof-probe: prints what the profiling-counter plugin sees, once per interval.
+//   gpumon-prof-probe [--interval-ms N] [--count N] [--lib PATH]
+// One line per GPU agent and window: percent of wall time the graphics engine and the MFMA
+// pipes were busy, the shader clock held, and the folded hardware counters behind them
+// ($GPUMON_PROF_EXTRA=A,B,C adds up to three SQ counters to look at).
+// The counters are device-wide: run a workload in another process and watch it here.
+#include <dlfcn.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../core/prof/prof_counters.h"
+
+int main(int argc, char** argv) {
+  int interval_ms = 1000, count = 5;
+  std::string lib;
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "--interval-ms") && i + 1 < argc) interval_ms = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--count") && i + 1 < argc) count = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--lib") && i + 1 < argc) lib = argv[++i];
+    else {
+      fprintf(stderr, "usage: %s [--interval-ms N] [--count N] [--lib PATH]\n", argv[0]);
+      return 2;
+    }
+  }
+  if (lib.empty()) {  // next to this binary: build/bin/.. = build/
+    char self[4096];
+    ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+    std::string dir = n > 0 ? std::string(self, (size_t)n) : std::string(".");
+    dir = dir.substr(0, dir.rfind('/'));
+    lib = dir + "/../libgpumon_prof.so";
+  }
+  void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!h) {
+    fprintf(stderr, "dlopen %s: %s\n", lib.c_str(), dlerror());
+    return 1;
+  }
+  auto open_fn = (decltype(&gmp_open))dlsym(h, "gmp_open");
+  auto info_fn = (decltype(&gmp_agent_info))dlsym(h, "gmp_agent_info");
+  auto sample_fn = (decltype(&gmp_sample))dlsym(h, "gmp_sample");
+  auto err_fn = (decltype(&gmp_last_error))dlsym(h, "gmp_last_error");
+  auto close_fn = (decltype(&gmp_close))dlsym(h, "gmp_close");
+  if (!open_fn || !info_fn || !sample_fn || !err_fn || !close_fn) {
+    fprintf(stderr, "%s: missing symbols\n", lib.c_str());
+    return 1;
+  }
+  char err[512] = "";
+  const int n = open_fn(err, sizeof err);
+  if (n < 0) {
+    fprintf(stderr, "gmp_open: %s\n", err);
+    return 1;
+  }
+  printf("agents: %d\n", n);
+  for (int a = 0; a < n; a++) {
+    gmp_agent_info_t ai;
+    if (info_fn(a, &ai) == 0)
+      printf("agent %d: %s  pci %04x:%02x:%02x.%x  cus %u  simds %u\n", a, ai.name, ai.pci_domain, (ai.pci_location >> 8) & 0xff,
+             (ai.pci_location >> 3) & 0x1f, ai.pci_location & 7, ai.cu_count, ai.simd_count);
+  }
+  fflush(stdout);
+  int rc = 0;
+  for (int i = 0; i <= count; i++) {
+    for (int a = 0; a < n; a++) {
+      gmp_sample_t s;
+      const int r = sample_fn(a, &s);
+      if (r < 0) {
+        fprintf(stderr, "agent %d: %s\n", a, err_fn());
+        rc = 1;
+      } else if (r == 0) {
+        printf("agent %d window %.3fs gpu_active %.2f mfma_active %.2f clock_mhz %.0f  raw count %.0f gui %.0f mfma %.0f extra %.0f %.0f %.0f\n",
+               a, s.window_s, s.gpu_active, s.mfma_active, s.clock_mhz, s.raw[0], s.raw[1], s.raw[2], s.raw[3], s.raw[4], s.raw[5]);
+      }
+    }
+    fflush(stdout);
+    if (i < count) usleep((useconds_t)interval_ms * 1000);
+  }
+  close_fn();
+  return rc;
+}

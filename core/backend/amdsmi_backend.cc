@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
+#include <cstring>
 #include <dlfcn.h>
 #include <map>
 #include <mutex>
@@ -22,6 +23,7 @@
 #include <amd_smi/amdsmi.h>
 
 #include "../common/util.h"
+#include "../prof/prof_counters.h"
 #include "backend.h"
 
 namespace gpumon {
@@ -139,6 +141,20 @@ struct Dev {
   // second however fast the profiling fields are watched, and not at all where the table is not readable.
   int64_t occupancy_read_mono = 0;
   double occupancy = std::nan("");
+  // Counter plugin (libgpumon_prof.so): agent of this device, last window's MFMA activity.
+  int prof_agent = -1;
+  int64_t prof_read_mono = 0;
+  double mfma_active = std::nan("");
+};
+
+// Entry points of the optional counter plugin (core/prof/prof_counters.h), resolved at run time.
+struct ProfApi {
+  void* lib = nullptr;
+  decltype(&::gmp_open) open = nullptr;
+  decltype(&::gmp_agent_info) agent_info = nullptr;
+  decltype(&::gmp_sample) sample = nullptr;
+  decltype(&::gmp_last_error) last_error = nullptr;
+  decltype(&::gmp_close) close = nullptr;
 };
 
 std::string sysfs_trim(const std::string& path) {
@@ -208,6 +224,8 @@ class AmdSmiBackend : public Backend {
     for (auto& d : devs_)
       if (d.events_on && api_.amdsmi_stop_gpu_event_notification) api_.amdsmi_stop_gpu_event_notification(d.h);
     api_.amdsmi_shut_down();
+    if (prof_.close) prof_.close();
+    prof_tried_ = false;  // a later init maps the plugin's agents onto the new device table
     inited_ = false;
     devs_.clear();
     // The library stays mapped: amdsmi keeps thread-local state that outlives shut_down.
@@ -435,6 +453,7 @@ class AmdSmiBackend : public Backend {
       return a.bdf_key != b.bdf_key ? a.bdf_key < b.bdf_key : a.partition_id < b.partition_id;
     });
     if (found.size() > GM_MAX_GPUS) found.resize(GM_MAX_GPUS);
+    prof_tried_ = false;  // the device table is rebuilt: map the counter plugin's agents again
     for (size_t i = 0; i < found.size(); i++) {
       found[i].st.index = (uint32_t)i;
       read_static(found[i]);
@@ -767,12 +786,79 @@ class AmdSmiBackend : public Backend {
       }
       if (!std::isnan(d.occupancy)) out->set_d(GM_FI_PROF_CU_OCCUPANCY, d.occupancy);
       else out->set_blank(GM_FI_PROF_CU_OCCUPANCY, GM_VS_NOT_SUPPORTED);
-      // Wave-level CU activity and MFMA pipe activity need device-wide hardware
-      // counters, which this backend does not program: blank, not estimated.
+      // Wave-level CU activity has no device-wide source (the SQ's wave counters only see the waves of the
+      // process that programs them): blank, not estimated.  MFMA pipe activity comes from the counter
+      // plugin when the operator has switched it on, and is blank otherwise.
       out->set_blank(GM_FI_PROF_CU_ACTIVE, GM_VS_NOT_SUPPORTED);
-      out->set_blank(GM_FI_PROF_MFMA_ACTIVE, GM_VS_NOT_SUPPORTED);
+      const double mfma = sample_prof_counters(d);
+      if (!std::isnan(mfma)) out->set_d(GM_FI_PROF_MFMA_ACTIVE, mfma);
+      else out->set_blank(GM_FI_PROF_MFMA_ACTIVE, GM_VS_NOT_SUPPORTED);
     }
     return true;
+  }
+
+  // Counter plugin: loaded on the first profiling sample if $GPUMON_PROF_COUNTERS is 1, never otherwise (it
+  // opens the compute runtime in this process).  Any failure is logged once and leaves the field blank.
+  void load_prof_plugin() {
+    prof_tried_ = true;
+    const char* on = getenv("GPUMON_PROF_COUNTERS");
+    if (!on || !*on || !strcmp(on, "0")) return;
+    std::vector<std::string> candidates;
+    if (const char* e = getenv("GPUMON_PROF_LIB"); e && *e) candidates.push_back(e);
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&blank_reason), &info) && info.dli_fname) {
+      std::string self = info.dli_fname;
+      const size_t slash = self.rfind('/');
+      candidates.push_back((slash == std::string::npos ? std::string(".") : self.substr(0, slash)) + "/libgpumon_prof.so");
+    }
+    candidates.push_back("libgpumon_prof.so");
+    for (auto& c : candidates)
+      if ((prof_.lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
+    if (!prof_.lib) {
+      GM_LOGW("profiling counters requested but libgpumon_prof.so did not load: %s", dlerror());
+      return;
+    }
+    prof_.open = reinterpret_cast<decltype(prof_.open)>(dlsym(prof_.lib, "gmp_open"));
+    prof_.agent_info = reinterpret_cast<decltype(prof_.agent_info)>(dlsym(prof_.lib, "gmp_agent_info"));
+    prof_.sample = reinterpret_cast<decltype(prof_.sample)>(dlsym(prof_.lib, "gmp_sample"));
+    prof_.last_error = reinterpret_cast<decltype(prof_.last_error)>(dlsym(prof_.lib, "gmp_last_error"));
+    prof_.close = reinterpret_cast<decltype(prof_.close)>(dlsym(prof_.lib, "gmp_close"));
+    char err[256] = "";
+    int n = -1;
+    if (!prof_.open || !prof_.agent_info || !prof_.sample || !prof_.last_error || !prof_.close || (n = prof_.open(err, sizeof err)) < 0) {
+      GM_LOGW("profiling counters unavailable: %s", err[0] ? err : "plugin has missing entry points");
+      prof_.sample = nullptr;
+      return;
+    }
+    // Agent <-> device by PCI address; partitions of one device are agents with the same address, in partition order.
+    std::vector<bool> taken((size_t)n, false);
+    for (auto& d : devs_)
+      for (int a = 0; a < n; a++) {
+        gmp_agent_info_t ai;
+        if (taken[(size_t)a] || prof_.agent_info(a, &ai) != 0) continue;
+        if ((((uint64_t)ai.pci_domain << 16) | ai.pci_location) != d.bdf_key) continue;
+        d.prof_agent = a;
+        taken[(size_t)a] = true;
+        break;
+      }
+    GM_LOGI("profiling counters on: %d agent(s) through rocprofiler-sdk", n);
+  }
+
+  double sample_prof_counters(Dev& d) {
+    if (!prof_tried_) load_prof_plugin();
+    if (!prof_.sample || d.prof_agent < 0) return std::nan("");
+    const int64_t now = monotonic_us();
+    if (d.prof_read_mono && now - d.prof_read_mono < 100000) return d.mfma_active;  // one window per 100 ms at most
+    d.prof_read_mono = now;
+    gmp_sample_t s;
+    const int rc = prof_.sample(d.prof_agent, &s);
+    if (rc == 0) d.mfma_active = s.mfma_active;
+    else if (rc < 0) {
+      d.mfma_active = std::nan("");
+      if (!prof_warned_) GM_LOGW("profiling counters: %s", prof_.last_error());
+      prof_warned_ = true;
+    }
+    return d.mfma_active;
   }
 
   bool sample_vram(Dev& d, Sample* out) {
@@ -908,6 +994,8 @@ class AmdSmiBackend : public Backend {
   SmiApi api_;
   std::mutex mu_;
   bool inited_ = false, events_tried_ = false, events_any_ = false;
+  ProfApi prof_;
+  bool prof_tried_ = false, prof_warned_ = false;
   std::vector<Dev> devs_;
 };
 

@@ -273,3 +273,86 @@ def test_micro_benchmarks(hw):
     assert res["engine.device_count_us"] < 50 and res["engine.device_attributes_us"] < 200
     assert res["engine.device_status_us"] < 200      # served from the sampler cache
     assert res["smi.device_status_us"] < 20000       # one full device-library round
+
+
+def test_mfma_activity_from_hardware_counters_follows_another_process_load(hw, tmp_path):
+    """dcgm_fi_prof_pipe_tensor_active on real hardware: the exporter, in a process of its own with
+    --prof-counters, programs the MFMA busy counter through libgpumon_prof.so (rocprofiler-sdk device
+    counting); the bf16 GEMM that loads the matrix pipes runs HERE, in another process.  Without the
+    flag the family is left out (blank), never 0."""
+    import re
+    import signal
+    import subprocess
+    from k8s_gpu_monitor_amd._lib import binary
+    from k8s_gpu_monitor_amd.ops import diag
+
+    def tensor_active(body):
+        fam = promparse.parse(body)
+        if "dcgm_fi_prof_pipe_tensor_active" not in fam:
+            return None
+        bdf_uuid = E.device_attributes(_engine_index_of_hip0())["uuid"]
+        for labels, v in fam["dcgm_fi_prof_pipe_tensor_active"].samples:
+            if labels["uuid"] == bdf_uuid:
+                return v
+        return None
+
+    def run_exporter(extra):
+        p = subprocess.Popen([binary("gpumon-exporter"), "-e", "-p", "-o", "", "-d", "250", "--listen", "127.0.0.1:0"] + extra,
+                             stderr=subprocess.PIPE, text=True, env=dict(os.environ, GPUMON_BACKEND="amdsmi"))
+        port = None
+        for _ in range(200):
+            line = p.stderr.readline()
+            m = re.search(r"Serving /metrics on port (\d+)", line or "")
+            if m:
+                port = int(m.group(1))
+                break
+            if not line:
+                break
+        assert port, "exporter did not come up"
+        return p, f"http://127.0.0.1:{port}/metrics"
+
+    def stop(p):
+        p.send_signal(signal.SIGTERM)
+        try:
+            p.wait(timeout=15)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+
+    fetch = lambda url: urllib.request.urlopen(url, timeout=5).read().decode()  # noqa: E731
+    p, url = run_exporter([])
+    try:
+        time.sleep(1.0)
+        assert tensor_active(fetch(url)) is None  # no counter source: blank
+    finally:
+        stop(p)
+
+    p, url = run_exporter(["--prof-counters"])
+    try:
+        torch.cuda.synchronize()
+        time.sleep(1.5)
+        idle = tensor_active(fetch(url))
+        assert idle is not None and idle < 5.0, idle
+        a, b = (torch.randn(8192, 8192, device="cuda:0").bfloat16() for _ in range(2))
+        c = torch.empty(8192, 8192, dtype=torch.bfloat16, device="cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        seen = []
+        t_end = time.time() + 3.0
+        while time.time() < t_end:
+            for _ in range(100):  # ~70 ms of GEMMs per batch
+                diag.gemm_launch("bf16", a.data_ptr(), b.data_ptr(), c.data_ptr(), 8192, 8192, 8192, stream)
+            torch.cuda.synchronize()
+            v = tensor_active(fetch(url))
+            if v is not None:
+                seen.append(v)
+        assert seen and max(seen) > 40.0, seen  # a bf16 GEMM at ~1.5 PFLOP/s keeps the pipes ~70 % busy
+        time.sleep(1.0)
+        after = tensor_active(fetch(url))
+        assert after is not None and after < 5.0, after
+        with open(f"/proc/{p.pid}/status") as f:
+            rss_kb = next(int(line.split()[1]) for line in f if line.startswith("VmRSS:"))
+        print(f"tensor_active idle {idle:.1f} load max {max(seen):.1f} median {statistics.median(seen):.1f} after {after:.1f}; "
+              f"exporter RSS with the counter plugin {rss_kb} kB")
+        assert rss_kb < 600_000
+    finally:
+        stop(p)
