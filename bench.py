@@ -51,9 +51,11 @@ class Sizes:
 class ExporterChild:
     """gpumon-exporter as a child process (started before this process touches the GPU)."""
 
-    def __init__(self, backend="amdsmi"):
+    def __init__(self, backend="amdsmi", prof_counters=False):
         from k8s_gpu_monitor_amd._lib import binary
         env = dict(os.environ, GPUMON_BACKEND=backend)
+        if prof_counters:  # MFMA pipe activity from hardware counters (libgpumon_prof.so inside the exporter)
+            env["GPUMON_PROF_COUNTERS"] = "1"
         if backend == "fake":
             env.setdefault("GPUMON_BACKEND_SPEC", "gpus=8,seed=1")
         self.proc = subprocess.Popen(
@@ -239,6 +241,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gemm-launches", type=int, default=8, help="GEMM launches per dtype per step")
     ap.add_argument("--no-exporter", action="store_true", help="debug: skip the exporter child and the scrape phase")
+    ap.add_argument("--prof-counters", action="store_true",
+                    help="the exporter also programs the MFMA busy counter (rocprofiler-sdk device counting) on every GPU")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo + fake backend with toy sizes: control-flow test only")
     a = ap.parse_args()
 
@@ -253,7 +257,7 @@ def main():
 
     exporter = None
     if rank == 0 and not a.no_exporter:
-        exporter = ExporterChild("fake" if a.dry_run else "amdsmi")  # before any HIP call in this process
+        exporter = ExporterChild("fake" if a.dry_run else "amdsmi", a.prof_counters)  # before any HIP call in this process
 
     import torch
     import torch.distributed as dist
@@ -403,7 +407,11 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
             "exporter_cpu_percent_of_one_core": round(100.0 * (cpu1 - cpu0) / elapsed, 2),
             "exporter_rss_kb": exporter.rss_kb(),
             "exporter_interval_ms": 1000,
+            "exporter_prof_counters": bool(a.prof_counters),
         })
+        m = re.search(rb'^dcgm_fi_prof_pipe_tensor_active\{gpu="0"[^}]*\} (\S+)', exporter.scrape()[1], re.M)
+        if m:
+            extras["tensor_active_percent_gpu0_last_scrape"] = float(m.group(1))
     if extras["memtest_errors"]:
         extras["FAILED"] = "memtest reported errors"
     gib = lambda b: f"{b / 2**30:g}GiB"  # noqa: E731

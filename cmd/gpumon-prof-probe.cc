@@ -5,11 +5,13 @@
 // ($GPUMON_PROF_EXTRA=A,B,C adds up to three SQ counters to look at).
 // The counters are device-wide: run a workload in another process and watch it here.
 #include <dlfcn.h>
+#include <sys/resource.h>
 #include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 
 #include "../core/prof/prof_counters.h"
@@ -62,21 +64,57 @@ int main(int argc, char** argv) {
   }
   fflush(stdout);
   int rc = 0;
+  auto cpu_s = []() {
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    return ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec) * 1e-6;
+  };
+  const double cpu_open = cpu_s();
+  double cpu_started = cpu_open;
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int i = 0; i <= count; i++) {
     for (int a = 0; a < n; a++) {
       gmp_sample_t s;
+      struct timespec c0, c1;
+      clock_gettime(CLOCK_MONOTONIC, &c0);
+      const double cpu0 = cpu_s();
       const int r = sample_fn(a, &s);
+      clock_gettime(CLOCK_MONOTONIC, &c1);
+      const double call_ms = (c1.tv_sec - c0.tv_sec) * 1e3 + (c1.tv_nsec - c0.tv_nsec) * 1e-6, call_cpu_ms = (cpu_s() - cpu0) * 1e3;
       if (r < 0) {
         fprintf(stderr, "agent %d: %s\n", a, err_fn());
         rc = 1;
       } else if (r == 0) {
-        printf("agent %d window %.3fs gpu_active %.2f mfma_active %.2f clock_mhz %.0f  raw count %.0f gui %.0f mfma %.0f extra %.0f %.0f %.0f\n",
-               a, s.window_s, s.gpu_active, s.mfma_active, s.clock_mhz, s.raw[0], s.raw[1], s.raw[2], s.raw[3], s.raw[4], s.raw[5]);
+        printf("agent %d window %.3fs gpu_active %.2f mfma_active %.2f clock_mhz %.0f  raw count %.0f gui %.0f mfma %.0f extra %.0f %.0f %.0f  (call %.1f ms wall, %.1f ms cpu)\n",
+               a, s.window_s, s.gpu_active, s.mfma_active, s.clock_mhz, s.raw[0], s.raw[1], s.raw[2], s.raw[3], s.raw[4], s.raw[5], call_ms, call_cpu_ms);
       }
     }
     fflush(stdout);
+    if (i == 0) {  // the first round only starts the counters: a one-time cost of its own
+      cpu_started = cpu_s();
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+    }
     if (i < count) usleep((useconds_t)interval_ms * 1000);
   }
+  struct timespec t1;
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  const double wall = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+  printf("cpu: %.3f s to open, %.3f s to start the counters, %.3f s over %.2f s of sampling (%.2f %% of one core)\n", cpu_open,
+         cpu_started - cpu_open, cpu_s() - cpu_started, wall, wall > 0 ? 100.0 * (cpu_s() - cpu_started) / wall : 0.0);
+  if (getenv("GPUMON_PROF_PROBE_THREADS")) {  // which thread the CPU time went to
+    char path[64];
+    snprintf(path, sizeof path, "/proc/%d/task", (int)getpid());
+    std::string cmd = std::string("for t in ") + path + "/*; do echo \"$(cat $t/comm) $(cut -d' ' -f14,15 $t/stat 2>/dev/null || awk '{print $14, $15}' $t/stat)\"; done";
+    fflush(stdout);
+    if (system(cmd.c_str()) != 0) rc = rc;
+  }
   close_fn();
+  if (const char* e = getenv("GPUMON_PROF_PROBE_AFTER_CLOSE_S")) {  // does the plugin cost anything with its counters stopped?
+    const double c0 = cpu_s();
+    const int secs = atoi(e);
+    sleep((unsigned)secs);
+    printf("cpu with the counters stopped: %.3f s over %d s\n", cpu_s() - c0, secs);
+  }
   return rc;
 }

@@ -233,13 +233,18 @@ int gmp_sample(int agent, gmp_sample_t* out) {
   size_t n = rec.size();
   rocprofiler_status_t st =
       rocprofiler_sample_device_counting_service(a.ctx, rocprofiler_user_data_t{}, ROCPROFILER_COUNTER_FLAG_NONE, rec.data(), &n);
-  // Restart whatever the read said, so that one bad read does not end the series.
-  rocprofiler_stop_context(a.ctx);
-  a.running = false;
   const double window_s = std::chrono::duration<double>(now - a.started).count();
-  if (rocprofiler_start_context(a.ctx) == ROCPROFILER_STATUS_SUCCESS) {
-    a.running = true;
-    a.started = std::chrono::steady_clock::now();
+  static const bool keep_running = getenv("GPUMON_PROF_KEEP_RUNNING") != nullptr;  // experiment: no stop/start between windows
+  if (!keep_running || st != ROCPROFILER_STATUS_SUCCESS) {
+    // Restart whatever the read said, so that one bad read does not end the series.
+    rocprofiler_stop_context(a.ctx);
+    a.running = false;
+    if (rocprofiler_start_context(a.ctx) == ROCPROFILER_STATUS_SUCCESS) {
+      a.running = true;
+      a.started = std::chrono::steady_clock::now();
+    }
+  } else {
+    a.started = now;
   }
   if (st != ROCPROFILER_STATUS_SUCCESS) {
     set_err("rocprofiler_sample_device_counting_service: %s", rocprofiler_get_status_string(st));

@@ -11,14 +11,16 @@ COPY Makefile ./
 COPY include include
 COPY core core
 COPY cmd cmd
-RUN make -j"$(nproc)" all
+RUN make -j"$(nproc)" all prof
 
 FROM rocm/dev-ubuntu-22.04:7.2
-COPY --from=build /src/build/libgpumon.so /usr/local/lib/
+COPY --from=build /src/build/libgpumon.so /src/build/libgpumon_prof.so /usr/local/lib/
 COPY --from=build /src/build/bin/gpumon /src/build/bin/gpumon-exporter /src/build/bin/gpumon-hostengine /usr/local/bin/
 RUN ldconfig
 VOLUME /run/prometheus
 EXPOSE 9400
 # Same default behaviour as the reference image: collect every second into
 # /run/prometheus/dcgm.prom with the engine in-process; also serve :9400/metrics.
+# Add "-p" for the profiling metrics and "--prof-counters" for MFMA pipe activity from hardware counters
+# (libgpumon_prof.so, next to libgpumon.so, is only loaded then).
 ENTRYPOINT ["gpumon-exporter", "-e", "--listen", ":9400"]
