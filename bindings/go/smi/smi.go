@@ -192,10 +192,12 @@ type Accounting struct {
 type Event struct {
 	GPU     uint
 	UUID    string
-	Code    uint
+	Code    uint // GM_EVENT_* code
 	Name    string
 	Message string
 	Time    time.Time
+	Etype   uint64 // 1 << Code: the bit RegisterEvent takes (the reference's Event.Etype)
+	Edata   uint64 // the code again (the reference's Event.Edata carries the XID number)
 }
 
 var ErrUnsupportedGPU = errors.New("unsupported GPU device")
@@ -427,8 +429,9 @@ func (d *Device) GetGraphicsRunningProcesses() ([]uint, []uint64, error) {
 // one round; entries are int64, float64, string or nil.
 func (d *Device) ReadFields(ids []uint16) ([]interface{}, error) { return readFields(d.Index, ids) }
 
-// WaitForEvent blocks up to timeout for the next driver event; (nil, nil) on timeout.
-func WaitForEvent(timeout time.Duration) (*Event, error) {
+// WaitForAnyEvent blocks up to timeout for the next driver event of any type on any GPU;
+// (nil, nil) on timeout.  WaitForEvent (events.go) is the filtered, reference-shaped form.
+func WaitForAnyEvent(timeout time.Duration) (*Event, error) {
 	e, err := eventWait(int(timeout / time.Millisecond))
 	if isStatus(err, StatusTimeout) {
 		return nil, nil
@@ -436,8 +439,8 @@ func WaitForEvent(timeout time.Duration) (*Event, error) {
 	if err != nil {
 		return nil, err
 	}
-	return &Event{GPU: e.gpu, UUID: e.uuid, Code: e.code, Name: eventName(e.code), Message: e.msg,
-		Time: time.UnixMicro(e.tsMicros)}, nil
+	ev := makeEvent(e)
+	return &ev, nil
 }
 
 func (d *Device) String() string {

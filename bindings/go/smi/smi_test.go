@@ -96,16 +96,39 @@ func TestFakeStatusOptionalValues(t *testing.T) {
 
 func TestFakeEventsAndProcesses(t *testing.T) {
 	defer withFake(t, "gpus=2")()
-	if e, err := WaitForEvent(50 * time.Millisecond); e != nil || err != nil {
+	if e, err := WaitForAnyEvent(50 * time.Millisecond); e != nil || err != nil {
 		t.Fatalf("expected a timeout, got %v %v", e, err)
 	}
 	go func() {
 		time.Sleep(50 * time.Millisecond)
 		_ = fakeCtl("event gpu=1 code=5 msg=ras")
 	}()
-	e, err := WaitForEvent(3 * time.Second)
+	e, err := WaitForAnyEvent(3 * time.Second)
 	if err != nil || e == nil || e.GPU != 1 || e.Code != 5 {
 		t.Fatalf("event: %+v %v", e, err)
+	}
+	// The reference's shape: an event set registered for critical errors of one device.
+	d1, _ := NewDeviceLite(1)
+	es := NewEventSet()
+	defer DeleteEventSet(es)
+	if err := RegisterEventForDevice(es, XidCriticalError, "no-such-uuid"); err == nil {
+		t.Fatal("an unknown UUID must be refused")
+	}
+	if err := RegisterEventForDevice(es, XidCriticalError, d1.UUID); err != nil {
+		t.Fatal(err)
+	}
+	if _, err := WaitForEvent(es, 50); !isStatus(err, StatusTimeout) {
+		t.Fatalf("expected a timeout status, got %v", err)
+	}
+	go func() {
+		time.Sleep(50 * time.Millisecond)
+		_ = fakeCtl("event gpu=0 code=5 msg=other-gpu") // filtered out: not registered for GPU 0
+		_ = fakeCtl("event gpu=1 code=2 msg=thermal")   // filtered out: not a critical error
+		_ = fakeCtl("event gpu=1 code=1 msg=vmfault")
+	}()
+	ev, err := WaitForEvent(es, 3000)
+	if err != nil || ev.UUID != d1.UUID || ev.Etype != EventVMFault || ev.Edata != 1 {
+		t.Fatalf("event set: %+v %v", ev, err)
 	}
 	_ = fakeCtl("proc_add gpu=0 pid=77 name=job vram=2147483648")
 	d, _ := NewDeviceLite(0)
