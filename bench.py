@@ -255,9 +255,14 @@ def main():
                      f"{a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
-    exporter = None
+    exporter, exporter_error = None, None
     if rank == 0 and not a.no_exporter:
-        exporter = ExporterChild("fake" if a.dry_run else "amdsmi", a.prof_counters)  # before any HIP call in this process
+        try:
+            exporter = ExporterChild("fake" if a.dry_run else "amdsmi", a.prof_counters)  # before any HIP call in this process
+        except (OSError, RuntimeError) as e:
+            # The kernels are still measured; the JSON says that the monitoring half is missing and why.
+            exporter_error = str(e)[-400:]
+            print(f"bench: exporter not started: {exporter_error}", file=sys.stderr)
 
     import torch
     import torch.distributed as dist
@@ -279,6 +284,8 @@ def main():
     try:
         kernels = (DryKernels if a.dry_run else GpuKernels)(torch, dev, sz, a.gemm_launches, rank)
         result = run(a, world, dev, exporter, torch, dist, kernels, sz, busbw_factor)
+        if exporter_error:
+            result["extras"]["exporter_error"] = exporter_error
     finally:
         if exporter:
             exporter.stop()
