@@ -1,4 +1,4 @@
-// libgpumon_prof.so: device-wide CU / MFMA / occupancy counters through rocprofiler-sdk's
+// libgpumon_prof.so: device-wide MFMA pipe activity (and the shader clock held) through rocprofiler-sdk's
 // device counting service.  See prof_counters.h for why this is a library of its own.
 //
 // One counting context per GPU agent, created inside the tool-initialisation callback

@@ -5,7 +5,9 @@
 // of the monitoring stack that opens the compute runtime (HSA) and programs performance
 // counters through rocprofiler-sdk's device counting service; libgpumon.so loads it with
 // dlopen only when the operator asks for it (GPUMON_PROF_COUNTERS=1 / --prof-counters),
-// and every field it feeds stays blank when it is absent or refused.
+// and every field it feeds stays blank when it is absent or refused.  It belongs in a
+// monitoring process: the registration has to precede the start of HSA, and the HIP runtime
+// of a process that has opened the plugin no longer finds a device (measured, ROCm 7.2).
 //
 // Reference: the DCGM "DCP" fields 1001-1005 the exporter passes through with -p
 // (exporters/prometheus-dcgm/dcgm-exporter/dcgm-exporter:80-83,179-187).

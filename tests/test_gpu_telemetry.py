@@ -356,3 +356,58 @@ def test_mfma_activity_from_hardware_counters_follows_another_process_load(hw, t
         assert rss_kb < 600_000
     finally:
         stop(p)
+
+
+def test_python_prof_wrapper_in_a_process_of_its_own(hw):
+    """ops.prof in a fresh interpreter that never touches HIP (after the plugin has registered with
+    rocprofiler-sdk and opened HSA, the HIP runtime of the same process finds no device: the plugin belongs in
+    a monitoring process); the bf16 GEMM it has to see runs here."""
+    import json
+    import subprocess
+    import sys
+    from k8s_gpu_monitor_amd.ops import diag
+    code = r"""
+import json, sys, time
+from k8s_gpu_monitor_amd.ops import prof
+agents = prof.open()
+assert prof.sample(0) is None
+time.sleep(0.5)
+idle = prof.sample(0)
+print(json.dumps({"agents": agents, "idle": idle}), flush=True)
+sys.stdin.readline()          # the parent starts its load, then asks for windows
+prof.sample(0)
+time.sleep(1.0)
+busy = prof.sample(0)
+prof.close()
+print(json.dumps({"busy": busy}), flush=True)
+"""
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    p = subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        first = json.loads(p.stdout.readline())
+        assert first["agents"] and first["agents"][0]["cu_count"] == 256 and first["agents"][0]["simd_count"] == 1024
+        assert first["idle"]["mfma_active"] < 5.0, first
+        a, b = (torch.randn(8192, 8192, device="cuda:0").bfloat16() for _ in range(2))
+        c = torch.empty(8192, 8192, dtype=torch.bfloat16, device="cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(50):
+            diag.gemm_launch("bf16", a.data_ptr(), b.data_ptr(), c.data_ptr(), 8192, 8192, 8192, stream)
+        p.stdin.write("go\n")
+        p.stdin.flush()
+        t_end = time.time() + 2.0
+        while time.time() < t_end:
+            for _ in range(100):
+                diag.gemm_launch("bf16", a.data_ptr(), b.data_ptr(), c.data_ptr(), 8192, 8192, 8192, stream)
+            torch.cuda.synchronize()
+        busy = json.loads(p.stdout.readline())["busy"]
+        assert busy["mfma_active"] > 40.0 and busy["gpu_active"] > 90.0, busy
+        assert 1000 < busy["clock_mhz"] < 2600, busy
+        assert p.wait(timeout=30) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+        err = p.stderr.read()
+        if p.returncode:
+            print(err[-2000:])

@@ -50,3 +50,16 @@ def test_exporter_flag_is_harmless_on_a_backend_without_counters():
     finally:
         p.send_signal(signal.SIGTERM)
         p.wait(timeout=15)
+
+
+def test_python_wrapper_refuses_politely_without_a_device():
+    """k8s_gpu_monitor_amd.ops.prof in a process of its own (the plugin opens the compute runtime)."""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        return
+    code = ("from k8s_gpu_monitor_amd.ops import prof\n"
+            "try:\n    prof.open()\nexcept prof.ProfError as e:\n    print('refused:', e)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "refused:" in r.stdout, (r.stdout, r.stderr)
