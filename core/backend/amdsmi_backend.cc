@@ -803,6 +803,14 @@ class AmdSmiBackend : public Backend {
     prof_tried_ = true;
     const char* on = getenv("GPUMON_PROF_COUNTERS");
     if (!on || !*on || !strcmp(on, "0")) return;
+    // A process that runs HIP work of its own cannot host the plugin: once the plugin has registered and opened
+    // HSA, the HIP runtime of the same process finds no device.  Leave the field blank there.
+    for (const char* hip : {"libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"})
+      if (void* h = dlopen(hip, RTLD_LAZY | RTLD_NOLOAD)) {
+        dlclose(h);
+        GM_LOGW("profiling counters requested, but this process has the HIP runtime loaded: not loading libgpumon_prof.so");
+        return;
+      }
     std::vector<std::string> candidates;
     if (const char* e = getenv("GPUMON_PROF_LIB"); e && *e) candidates.push_back(e);
     Dl_info info;

@@ -12,8 +12,9 @@
 // process): the GRBM counters and the MFMA pipe's busy cycles count all work on the device;
 // the SQ counters that count waves or their instructions (SQ_WAVES, SQ_BUSY_CYCLES,
 // SQ_BUSY_CU_CYCLES, SQ_WAVE_CYCLES, SQ_LEVEL_WAVES) stay at zero for waves of other
-// processes, whose queues do not carry the per-wave counting enable.  They are therefore
-// not collected, and CU activity / wave occupancy are not reported from here.
+// processes, whose queues do not carry the per-wave counting enable, and so do the L2's
+// memory-request counters (TCC_EA0_RDREQ / WRREQ) under another process's HBM stream.  They are
+// therefore not collected, and CU activity / wave occupancy / memory traffic are not reported from here.
 #include "prof_counters.h"
 
 #include <hsa/hsa.h>
