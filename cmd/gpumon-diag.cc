@@ -6,7 +6,7 @@
 //   gpumon-diag hbm    [-g GPU] [--bytes N] [--iters N] [--kernel NAME|all] [--min-tbps X]
 //   gpumon-diag memtest[-g GPU] [--bytes N | --fraction F] [--patterns a,b] [--passes N]
 //   gpumon-diag mfma   [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]
-//   gpumon-diag gemm   [-g GPU] [--dtype bf16|mxfp8|fp8] [--m M --n N --k K] [--seconds S] [--no-telemetry]
+//   gpumon-diag gemm   [-g GPU] [--dtype bf16|mxfp8|fp8] [--m M --n N --k K] [--seconds S] [--no-telemetry] [--mfma-counters]
 //   gpumon-diag rccl   [--gpus 0,1,..] [--ops a,b] [--min-bytes N] [--max-bytes N] [--scaling]
 //   gpumon-diag p2p    [--gpus 0,1,..] [--bytes N]
 //   gpumon-diag run -r 1|2|3 [-g GPU]      graded suites: quick / medium / long
@@ -14,6 +14,9 @@
 // `gpumon-exporter --diag-results` picks it up and exports it as gpumon_diag_* metrics).
 // Exit status: 0 pass, 1 a test failed, 2 usage / setup error.
 #include <unistd.h>
+#include <signal.h>
+#include <spawn.h>
+#include <sys/wait.h>
 
 #include <strings.h>
 
@@ -295,6 +298,89 @@ int cmd_mfma(const Args& a, Report& r) {
   return 0;
 }
 
+// Matrix-pipe activity during a soak, from the MFMA busy-cycle hardware counter.  The counter plugin cannot
+// live in a process that runs HIP work (core/prof/prof_counters.h), so `gpumon-prof-probe` runs as a child and
+// its lines are read from a pipe: "agent N: name  pci dddd:bb:dd.f ..." once, then per 250 ms window
+// "agent N window Ws gpu_active X mfma_active Y clock_mhz Z ...".
+struct MfmaWatch {
+  pid_t pid = -1;
+  int fd = -1;
+  std::thread reader;
+  std::map<int, std::string> bdf_of;             // agent -> pci address
+  std::map<int, std::vector<double>> mfma, mhz;  // agent -> windows
+  bool start() {
+    char self[4096];
+    ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+    if (n <= 0) return false;
+    std::string probe(self, (size_t)n);
+    probe = probe.substr(0, probe.rfind('/')) + "/gpumon-prof-probe";
+    if (access(probe.c_str(), X_OK) != 0) return false;
+    int pfd[2];
+    if (pipe(pfd) != 0) return false;
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, pfd[1], 1);
+    posix_spawn_file_actions_addclose(&fa, pfd[0]);
+    posix_spawn_file_actions_addclose(&fa, pfd[1]);
+    const char* argv[] = {probe.c_str(), "--interval-ms", "250", "--count", "1000000", nullptr};
+    const int rc = posix_spawn(&pid, probe.c_str(), &fa, nullptr, const_cast<char* const*>(argv), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    close(pfd[1]);
+    if (rc != 0) {
+      close(pfd[0]);
+      pid = -1;
+      return false;
+    }
+    fd = pfd[0];
+    reader = std::thread([this] {
+      FILE* f = fdopen(fd, "r");
+      if (!f) return;
+      char line[1024];
+      while (fgets(line, sizeof line, f)) {
+        int agent = 0;
+        char name[64], bdf[32];
+        double w, ga, ma, mz;
+        if (sscanf(line, "agent %d: %63s pci %31s", &agent, name, bdf) == 3) bdf_of[agent] = bdf;
+        else if (sscanf(line, "agent %d window %lfs gpu_active %lf mfma_active %lf clock_mhz %lf", &agent, &w, &ga, &ma, &mz) == 5) {
+          mfma[agent].push_back(ma);
+          mhz[agent].push_back(mz);
+        }
+      }
+      fclose(f);
+    });
+    return true;
+  }
+  // Ends the child and folds the windows of the device with this PCI address; the first window after the
+  // start and the last one (cut short by the end of the soak) are left out when there are enough.
+  std::string finish(Report& r, const char* pci_bdf) {
+    if (pid < 0) return "null";
+    kill(pid, SIGTERM);
+    int st = 0;
+    waitpid(pid, &st, 0);
+    pid = -1;
+    if (reader.joinable()) reader.join();
+    for (auto& kv : bdf_of) {
+      if (strcasecmp(kv.second.c_str(), pci_bdf) != 0) continue;
+      std::vector<double> v = mfma[kv.first], c = mhz[kv.first];
+      if (v.size() > 4) v = std::vector<double>(v.begin() + 1, v.end() - 1), c = std::vector<double>(c.begin() + 1, c.end() - 1);
+      if (v.empty()) break;
+      auto fold = [](const std::vector<double>& x, double* lo, double* avg, double* hi) {
+        *lo = 1e300, *hi = -1e300, *avg = 0;
+        for (double e : x) *lo = std::min(*lo, e), *hi = std::max(*hi, e), *avg += e / x.size();
+      };
+      double lo, avg, hi, clo, cavg, chi;
+      fold(v, &lo, &avg, &hi);
+      fold(c, &clo, &cavg, &chi);
+      r.text("  matrix pipes (MFMA busy counter, 250 ms windows): min %5.1f  avg %5.1f  max %5.1f %% busy at %4.0f MHz  (%d windows)\n", lo,
+             avg, hi, cavg, (int)v.size());
+      return "{\"min\":" + jnum(lo) + ",\"avg\":" + jnum(avg) + ",\"max\":" + jnum(hi) + ",\"clock_mhz\":" + jnum(cavg) +
+             ",\"windows\":" + std::to_string(v.size()) + "}";
+    }
+    r.text("  matrix pipes: the counter probe gave no windows for this device\n");
+    return "null";
+  }
+};
+
 // Engine-side telemetry of the GPU under stress: power / temperature / clocks at 100 ms.
 struct Soak {
   bool on = false;
@@ -376,15 +462,23 @@ int cmd_gemm(const Args& a, Report& r) {
   const std::string which = a.str("--dtype", "bf16,mxfp8");
   const int m = (int)a.num("--m", 8192), n = (int)a.num("--n", 8192), k = (int)a.num("--k", 8192);
   const double secs = a.num("--seconds", 5.0), floor_tf = a.num("--min-tflops", 0);
+  MfmaWatch mfma;  // started first: a child process, before this one has touched the device
+  const bool want_mfma = a.has("--mfma-counters") && mfma.start();
+  if (a.has("--mfma-counters") && !want_mfma) fprintf(stderr, "note: gpumon-prof-probe not found next to this binary; no matrix-pipe counters\n");
   Soak soak;
   if (!a.has("--no-telemetry") && !soak.start(gpu)) fprintf(stderr, "note: engine telemetry unavailable; running without it\n");
   std::string obj = "{";
   bool any = false;
+  auto end_watch = [&] {
+    gmd_device_info_t d;
+    if (want_mfma) r.member("mfma_active", mfma.finish(r, gmd_device_info(gpu, &d) == GMD_OK ? d.pci_bdf : ""));
+  };
   for (auto& name : csv(which)) {
     int dt = dtype_of(name);
     if (dt < 0 || dt == GMD_DT_F32) {
       fprintf(stderr, "unknown GEMM dtype %s\n", name.c_str());
       soak.stop();
+      end_watch();
       return 2;
     }
     gmd_mfma_result_t g;
@@ -392,6 +486,7 @@ int cmd_gemm(const Args& a, Report& r) {
     if (rc != GMD_OK && rc != GMD_ERR_VERIFY) {
       fprintf(stderr, "error: gemm stress -> %d: %s\n", rc, gmd_last_error());
       soak.stop();
+      end_watch();
       return 2;
     }
     r.text("GEMM stress %s %dx%dx%d on GPU %d: %.1f TFLOP/s (best %.1f), %llu launches in %.1f s, sdc mismatches %llu, check %s\n",
@@ -409,6 +504,7 @@ int cmd_gemm(const Args& a, Report& r) {
   r.member("gemm_stress", obj + "}");
   r.member("telemetry", soak.summarize(r));
   soak.stop();
+  end_watch();
   return 0;
 }
 
@@ -572,7 +668,7 @@ void usage() {
           "  hbm     [-g GPU] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
           "  memtest [-g GPU] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N]\n"
           "  mfma    [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
-          "  gemm    [-g GPU] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--min-tflops X] [--no-telemetry]\n"
+          "  gemm    [-g GPU] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--min-tflops X] [--no-telemetry] [--mfma-counters]\n"
           "  rccl    [--gpus LIST] [--ops LIST] [--min-bytes N] [--max-bytes N] [--factor N] [--iters N] [--scaling] [--no-verify] [--min-busbw GBPS]\n"
           "  p2p     [--gpus LIST] [--bytes N] [--iters N]\n"
           "  run     -r 1|2|3 [-g GPU]\n");

@@ -44,6 +44,7 @@ const char* help_of(const std::string& fam) {
       {"gpumon_diag_soak_power_watts", "Board power during the GEMM soak (min / avg / max)."},
       {"gpumon_diag_soak_gfx_clock_mhz", "Shader clock held during the GEMM soak (min / avg / max)."},
       {"gpumon_diag_soak_gpu_temp_celsius", "Hotspot temperature during the GEMM soak (min / avg / max)."},
+      {"gpumon_diag_soak_mfma_active_percent", "Matrix (MFMA) pipe busy during the GEMM soak, from the hardware counter (min / avg / max)."},
       {"gpumon_diag_rccl_busbw_gbps", "Peak RCCL bus bandwidth per collective (in GB/s)."},
       {"gpumon_diag_p2p_gbps", "Peer copy bandwidth between two GPUs (in GB/s)."},
   };
@@ -88,6 +89,10 @@ void parse_report(const Json& r, Families* f) {
           for (const char* stat : {"min", "avg", "max"})
             if (v->get(stat)) add(s.fam, std::string("stat=\"") + stat + "\"", num(v->get(stat)));
     }
+  if (const Json* v = r.get("mfma_active"))
+    if (v->type == Json::OBJ)
+      for (const char* stat : {"min", "avg", "max"})
+        if (v->get(stat)) add("gpumon_diag_soak_mfma_active_percent", std::string("stat=\"") + stat + "\"", num(v->get(stat)));
   auto rccl = [&](const Json& sweep) {
     const int n = (int)num(sweep.get("gpus"), 0);
     if (const Json* pk = sweep.get("peak_busbw_gbps"))

@@ -266,6 +266,30 @@ def test_cli_report_is_published_and_exported(tmp_path):
     assert fams["gpumon_diag_memtest_bytes"].samples[0][1] == float(1 << 30)
 
 
+def test_soak_reports_matrix_pipe_activity_from_the_hardware_counter(tmp_path):
+    """gpumon-diag gemm --mfma-counters: the counter probe runs as a child next to the soak; the report carries
+    the MFMA busy percentage and the exporter turns it into gpumon_diag_soak_mfma_active_percent."""
+    import json
+    import os
+    import subprocess
+    from conftest import bin_path
+    from k8s_gpu_monitor_amd.utils.promparse import parse
+    rep, out = tmp_path / "gpu0.json", tmp_path / "m.prom"
+    r = subprocess.run([bin_path("gpumon-diag"), "gemm", "--dtype", "bf16", "--seconds", "3", "--mfma-counters", "--publish", str(rep)],
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "matrix pipes (MFMA busy counter" in r.stdout
+    m = json.loads(rep.read_text())["mfma_active"]
+    assert m["windows"] >= 4 and 40.0 < m["avg"] <= 100.0 and m["max"] >= m["avg"] >= m["min"], m
+    assert 1000 < m["clock_mhz"] < 2600
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=1,steady=1")
+    r = subprocess.run([bin_path("gpumon-exporter"), "-e", "--once", "-o", str(out), "--diag-results", str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0, r.stderr
+    stats = {l["stat"]: v for l, v in parse(out.read_text())["gpumon_diag_soak_mfma_active_percent"].samples}
+    assert stats["avg"] == pytest.approx(m["avg"], abs=0.01)
+
+
 def test_torch_distributed_sweep_on_rccl(dev):
     import os
     import torch.distributed as dist
