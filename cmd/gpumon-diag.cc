@@ -24,7 +24,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <ctime>
+#include <chrono>
 #include <map>
+#include <mutex>
 #include <thread>
 
 #include "../diag/gpumon_diag.h"
@@ -308,6 +310,24 @@ struct MfmaWatch {
   std::thread reader;
   std::map<int, std::string> bdf_of;             // agent -> pci address
   std::map<int, std::vector<double>> mfma, mhz;  // agent -> windows
+  std::map<int, std::vector<double>> at;         // agent -> arrival time of each window (steady clock, s)
+  std::mutex mu;
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  // Average MFMA activity over the windows that lie wholly inside [t0, t1] (a window arrives when it ends and
+  // is 250 ms long); -1 when there is none.
+  double average_between(const char* pci_bdf, double t0, double t1, int* windows) {
+    std::lock_guard<std::mutex> l(mu);
+    double sum = 0;
+    int n = 0;
+    for (auto& kv : bdf_of) {
+      if (strcasecmp(kv.second.c_str(), pci_bdf) != 0) continue;
+      const auto &v = mfma[kv.first], &t = at[kv.first];
+      for (size_t i = 0; i < v.size() && i < t.size(); i++)
+        if (t[i] - 0.26 >= t0 && t[i] <= t1 + 0.02) sum += v[i], n++;
+    }
+    *windows = n;
+    return n ? sum / n : -1.0;
+  }
   bool start() {
     char self[4096];
     ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
@@ -340,10 +360,12 @@ struct MfmaWatch {
         int agent = 0;
         char name[64], bdf[32];
         double w, ga, ma, mz;
+        std::lock_guard<std::mutex> l(mu);
         if (sscanf(line, "agent %d: %63s pci %31s", &agent, name, bdf) == 3) bdf_of[agent] = bdf;
         else if (sscanf(line, "agent %d window %lfs gpu_active %lf mfma_active %lf clock_mhz %lf", &agent, &w, &ga, &ma, &mz) == 5) {
           mfma[agent].push_back(ma);
           mhz[agent].push_back(mz);
+          at[agent].push_back(now());
         }
       }
       fclose(f);
@@ -482,7 +504,9 @@ int cmd_gemm(const Args& a, Report& r) {
       return 2;
     }
     gmd_mfma_result_t g;
+    const double t_begin = MfmaWatch::now();
     int rc = gmd_gemm_stress(gpu, dt, m, n, k, secs, 1, &g);
+    const double t_end = MfmaWatch::now();
     if (rc != GMD_OK && rc != GMD_ERR_VERIFY) {
       fprintf(stderr, "error: gemm stress -> %d: %s\n", rc, gmd_last_error());
       soak.stop();
@@ -495,7 +519,18 @@ int cmd_gemm(const Args& a, Report& r) {
     obj += std::string(any ? "," : "") + "\"" + name + "\":{\"tflops\":" + jnum(g.tflops) + ",\"tflops_best\":" +
            jnum(g.tflops_best) + ",\"launches\":" + std::to_string(g.launches) + ",\"sdc_mismatches\":" +
            std::to_string(g.sdc_mismatches) + ",\"max_rel_err\":" + jnum(g.max_rel_err) + ",\"verified\":" +
-           std::to_string(g.verified) + "}";
+           std::to_string(g.verified);
+    if (want_mfma) {  // the windows that lie inside this dtype's soak
+      usleep(300000);  // let the window that ends with the soak arrive
+      gmd_device_info_t d;
+      int wn = 0;
+      const double avg = gmd_device_info(gpu, &d) == GMD_OK ? mfma.average_between(d.pci_bdf, t_begin, t_end, &wn) : -1.0;
+      if (wn > 0) {
+        r.text("  matrix pipes during the %s soak: %.1f %% busy (MFMA busy counter, %d windows)\n", name.c_str(), avg, wn);
+        obj += ",\"mfma_active_avg\":" + jnum(avg);
+      }
+    }
+    obj += "}";
     any = true;
     if (g.verified < 0) r.fail("GEMM %s result does not match the reference", name.c_str());
     if (g.sdc_mismatches) r.fail("GEMM %s: %llu launches changed their checksum (silent data corruption)", name.c_str(), (unsigned long long)g.sdc_mismatches);

@@ -44,6 +44,7 @@ const char* help_of(const std::string& fam) {
       {"gpumon_diag_soak_power_watts", "Board power during the GEMM soak (min / avg / max)."},
       {"gpumon_diag_soak_gfx_clock_mhz", "Shader clock held during the GEMM soak (min / avg / max)."},
       {"gpumon_diag_soak_gpu_temp_celsius", "Hotspot temperature during the GEMM soak (min / avg / max)."},
+      {"gpumon_diag_gemm_mfma_active_percent", "Matrix (MFMA) pipe busy during the GEMM stress of one data type, from the hardware counter (average)."},
       {"gpumon_diag_soak_mfma_active_percent", "Matrix (MFMA) pipe busy during the GEMM soak, from the hardware counter (min / avg / max)."},
       {"gpumon_diag_rccl_busbw_gbps", "Peak RCCL bus bandwidth per collective (in GB/s)."},
       {"gpumon_diag_p2p_gbps", "Peer copy bandwidth between two GPUs (in GB/s)."},
@@ -78,6 +79,8 @@ void parse_report(const Json& r, Families* f) {
     for (auto& kv : g->obj) {
       add("gpumon_diag_gemm_tflops", "dtype=\"" + kv.first + "\"", num(kv.second.get("tflops")));
       add("gpumon_diag_gemm_sdc_mismatches", "dtype=\"" + kv.first + "\"", num(kv.second.get("sdc_mismatches")));
+      if (kv.second.get("mfma_active_avg"))
+        add("gpumon_diag_gemm_mfma_active_percent", "dtype=\"" + kv.first + "\"", num(kv.second.get("mfma_active_avg")));
     }
   if (const Json* t = r.get("telemetry"))
     if (t->type == Json::OBJ) {

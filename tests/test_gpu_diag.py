@@ -279,7 +279,9 @@ def test_soak_reports_matrix_pipe_activity_from_the_hardware_counter(tmp_path):
                        capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "matrix pipes (MFMA busy counter" in r.stdout
-    m = json.loads(rep.read_text())["mfma_active"]
+    report = json.loads(rep.read_text())
+    assert 40.0 < report["gemm_stress"]["bf16"]["mfma_active_avg"] <= 100.0  # the windows inside the bf16 soak alone
+    m = report["mfma_active"]
     assert m["windows"] >= 4 and 40.0 < m["avg"] <= 100.0 and m["max"] >= m["avg"] >= m["min"], m
     assert 1000 < m["clock_mhz"] < 2600
     env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=1,steady=1")
