@@ -5,6 +5,8 @@
 // ($GPUMON_PROF_EXTRA=A,B,C adds up to three SQ counters to look at).
 // The counters are device-wide: run a workload in another process and watch it here.
 #include <dlfcn.h>
+#include <sys/prctl.h>
+#include <signal.h>
 #include <sys/resource.h>
 #include <unistd.h>
 
@@ -17,6 +19,7 @@
 #include "../core/prof/prof_counters.h"
 
 int main(int argc, char** argv) {
+  prctl(PR_SET_PDEATHSIG, SIGTERM);  // started as a child by gpumon-diag: never outlive the run it watches
   int interval_ms = 1000, count = 5;
   std::string lib;
   for (int i = 1; i < argc; i++) {
