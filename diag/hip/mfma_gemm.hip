@@ -263,6 +263,43 @@ __device__ __forceinline__ void quadrant(f32x4 (&acc)[8][4], const i32x8 (&a)[4]
   }
 }
 
+// Store a wave's accumulators as bf16.  Each lane holds four consecutive N elements (8 bytes) of one row per
+// 16 x 16 block; EPI = 0 stores them as they are (32 stores of 8 bytes per lane).  EPI = 1 first exchanges
+// halves between neighbouring 16-lane rows of two adjacent blocks (v_permlane16_swap: odd rows of the first
+// operand <-> even rows of the second), after which every lane holds eight consecutive elements of one block and
+// stores 16 bytes: half the store instructions for the same bytes and addresses.  EPI = 1 also marks the stores
+// non-temporal (C is never read back); EPI = 2 leaves them cached.
+template <int NBLK, int EPI>
+__device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* __restrict__ C, size_t ldc, int m0, int nbase,
+                                          int fq) {
+  if constexpr (EPI == 0) {
+#pragma unroll
+    for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+      for (int nb = 0; nb < NBLK; nb++) {
+        bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
+        *(bf16x4*)(C + (size_t)(m0 + mb * 16) * ldc + nbase + fq * 4 + nb * 16) = o;
+      }
+  } else {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int col = nbase + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+    for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+      for (int nb = 0; nb < NBLK; nb += 2) {
+        u32x2 x = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb], bf16x4));
+        u32x2 y = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb + 1], bf16x4));
+        const u32x2 r0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+        const u32x2 r1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+        const u32x4 o = u32x4{r0.x, r1.x, r0.y, r1.y};
+        u32x4* dst = (u32x4*)(C + (size_t)(m0 + mb * 16) * ldc + col + nb * 16);
+        if constexpr (EPI == 1) __builtin_nontemporal_store(o, dst);
+        else *dst = o;
+      }
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -286,7 +323,8 @@ __device__ unsigned long long g_gemm_timeline[4 * kStampSlots];
 // ABL is for timing-only ablation builds (make diag-ablate; results are wrong by design):
 // bit 0 drops the fragment reads of the loop, bit 1 the LDS-DMA and its waits, bit 2 the MFMAs;
 // bit 3 points every workgroup at the operands of tile (0, 0) (an always-L2-resident stream).
-template <int DT, int ABL = 0, int AHEAD = kAheadDefault, bool PERSIST = false>
+// EPI: see store_acc.
+template <int DT, int ABL = 0, int AHEAD = kAheadDefault, int EPI = 1>
 __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
   constexpr int kAhead = AHEAD;  // half-tiles issued ahead of the running phase; kAhead - 2 of them are in flight
@@ -295,18 +333,11 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  // Tiles are dealt to the XCDs in contiguous chunks (bijective for any count).  One workgroup per tile, or
-  // (PERSIST) a grid of one workgroup per CU in which workgroup j of an XCD walks tiles j, j + G/8, ... of the
-  // XCD's chunk: the XCD still works on G/8 neighbouring tiles at any time, and a workgroup fetches the first
-  // half-tiles of its next tile before it stores the finished one.
+  // Tiles are dealt to the XCDs in contiguous chunks (bijective for any count), one workgroup per tile.
   const int tiles_m = M / BM, tiles_n = N / BN;
-  const int total = PERSIST ? tiles_m * tiles_n : (int)gridDim.x;
+  const int total = (int)gridDim.x;
   const int xcd = blockIdx.x & 7, q8 = total >> 3, r8n = total & 7;
-  const int chunk0 = xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8;
-  const int chunk_end = chunk0 + q8 + (xcd < r8n ? 1 : 0);
-  const int tile_step = PERSIST ? max((int)gridDim.x >> 3, 1) : total;
-  int wgid = chunk0 + (int)(blockIdx.x >> 3);
-  if (wgid >= chunk_end) return;  // whole workgroup, before any barrier
+  const int wgid = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (int)(blockIdx.x >> 3);
   int tm, tn;
   tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
 #ifdef GMD_GEMM_ABLATE
@@ -443,95 +474,277 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
   using T = std::integral_constant<int, 1>;
 
   issue_prologue();
-  for (;;) {
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  wait_vmcnt<2 * (kAhead - 2)>();  // half-tiles 0 and 1 landed
+  GMD_PHASE_FENCE();
+  read_b(bp, 0);  // B-lo of K-tile 0
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (wr == 1) { GMD_PHASE_FENCE(); }  // run the second wave row one barrier behind the first
+
+  for (int it = 0; it + 1 < npairs; it++) {
+    const int kt0 = 2 * it;
+    phase(std::integral_constant<int, 0>{}, F{}, kt0);
+    phase(std::integral_constant<int, 1>{}, F{}, kt0);
+    phase(std::integral_constant<int, 2>{}, F{}, kt0);
+    phase(std::integral_constant<int, 3>{}, F{}, kt0);
+    phase(std::integral_constant<int, 4>{}, F{}, kt0);
+    phase(std::integral_constant<int, 5>{}, F{}, kt0);
+    phase(std::integral_constant<int, 6>{}, F{}, kt0);
+    phase(std::integral_constant<int, 7>{}, F{}, kt0);
+  }
+  {
+    const int kt0 = 2 * (npairs - 1);
+    phase(std::integral_constant<int, 0>{}, T{}, kt0);
+    phase(std::integral_constant<int, 1>{}, T{}, kt0);
+    phase(std::integral_constant<int, 2>{}, T{}, kt0);
+    phase(std::integral_constant<int, 3>{}, T{}, kt0);
+    phase(std::integral_constant<int, 4>{}, T{}, kt0);
+    phase(std::integral_constant<int, 5>{}, T{}, kt0);
+    phase(std::integral_constant<int, 6>{}, T{}, kt0);
+    phase(std::integral_constant<int, 7>{}, T{}, kt0);
+  }
+  if (wr == 0) { GMD_PHASE_FENCE(); }  // the barrier the second wave row took up front
+#ifdef GMD_GEMM_ABLATE
+  if constexpr (ABL & 16) {
+    asm volatile("s_nop 0" ::"v"(acc[7][3]));  // stamp behind the last MFMA's result
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && wgid < kStampSlots) {
+      g_gemm_stamps[2 * wgid] = t1 - stamp_t0;
+      g_gemm_stamps[2 * wgid + 1] = r1 - stamp_r0;
+    }
+  }
+#endif
+  store_acc<4, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 64, fq);
+}
+
+// ---- (2b') the eight-wave pipeline as one unbroken stream over a workgroup's tiles ----
+//
+// One workgroup per CU walks its tiles as in the persistent form of gemm_pp_kernel, but the ring never
+// drains between tiles: half-tile numbering simply continues, so the last K-tile pair of a tile already
+// issues the first seven half-tiles of the next tile into the slots they would have had anyway, and its last
+// phase reads the next tile's first B fragments.  Between the last MFMA of one tile and the first of the next
+// a wave only converts and stores its accumulators; it waits for neither the stores nor any fetch.
+//
+// The stores share the wave's vector-memory counter with the LDS-DMA, and the counter retires in issue
+// order.  Behind an epilogue the sequence a wave has outstanding is
+//     [half-tiles q+3 .. 6] [kStores stores] [half-tiles 7 .. q+7]        (q = phases since the epilogue)
+// so for q = 0..4 "all but the youngest 10 + kStores" is exactly "half-tiles up to q+2 have landed", with the
+// stores free to drain behind the MFMAs; from q = 5 on the wait is the steady-state one (by then the stores are
+// ~1.6 us old).  The two wave rows keep their one-barrier stagger across tiles: a row stores while the other
+// row runs its MFMAs.
+template <int DT, int EPI = 1, int ABL = 0>  // ABL 16: clock stamps and per-tile timeline (ablation builds only)
+__global__ __launch_bounds__(kThreads) void gemm_ps_kernel(const char* __restrict__ A, const char* __restrict__ B,
+                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+  constexpr int kAhead = kAheadDefault;
+  static_assert(kAhead == 7, "the mode tables below are written for an issue distance of seven half-tiles");
+  constexpr int kStores = EPI ? 16 : 32;  // store instructions per wave of one tile (store_acc)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // XCD x owns a contiguous chunk of tiles; its workgroup j walks tiles j, j + G/8, ... of the chunk.
+  const int tiles_m = M / BM, tiles_n = N / BN, total = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, q8 = total >> 3, r8n = total & 7;
+  const int chunk0 = xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8;
+  const int chunk_end = chunk0 + q8 + (xcd < r8n ? 1 : 0);
+  const int tile_step = max((int)gridDim.x >> 3, 1);
+  int wgid = chunk0 + (int)(blockIdx.x >> 3);
+  if (wgid >= chunk_end) return;  // whole workgroup, before any barrier
+  int tm, tn;
+  tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
+  const char* gA = A + (size_t)tm * BM * row_bytes;
+  const char* gB = B + (size_t)tn * BN * row_bytes;
+  const char* nA = gA;
+  const char* nB = gB;
+
+  // Staging and fragment addressing: as in gemm_pp_kernel.
+  const int r8 = lane >> 3;
+  const uint32_t src_chunk = (uint32_t)(((lane & 7) ^ chunk_swizzle<DT>(r8)) * 16);
+  uint32_t off_a[2], off_b[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int l = (2 * wave + i) * 8 + r8;
+    off_a[i] = (uint32_t)(((l >> 6) * 128 + (l & 63)) * row_bytes) + src_chunk;
+    off_b[i] = (uint32_t)(((l >> 5) * 64 + (l & 31)) * row_bytes) + src_chunk;
+  }
+  const size_t hi_a = 64 * row_bytes, hi_b = 32 * row_bytes;
+  char* const my_pieces = smem + wave * 2048;
+  // kind: 0 B-lo, 1 A-lo, 2 B-hi, 3 A-hi;  par: ring half;  kt: K-tile index inside the tile whose panels pa / pb are
+  auto issue = [&](auto KIND, auto PAR, const char* pa, const char* pb, int kt) {
+    constexpr int kind = decltype(KIND)::value, par = decltype(PAR)::value;
+    const char* base = ((kind & 1) ? pa + (kind == 3 ? hi_a : 0) : pb + (kind == 2 ? hi_b : 0)) + (size_t)kt * BKB;
+    asm volatile("" : "+s"(base));  // wave-uniform part of the address in scalar registers
+    char* dst = my_pieces + (par * 4 + kind) * kHalfBytes;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + ((kind & 1) ? off_a[i] : off_b[i])),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    const int ch = DT == GMD_DT_BF16 ? ks * 4 + fq : 2 * fq + ks;
+    a_off[ks] = lds_off<DT>(wr * 64 + fr, ch);
+    b_off[ks] = lds_off<DT>(wc * 32 + fr, ch);
+  }
+  auto read_a = [&](i32x8 (&a)[4], int slot) {
+#pragma unroll
+    for (int mb = 0; mb < 4; mb++) {
+      const i32x4 lo = *(const i32x4*)(smem + slot * kHalfBytes + a_off[0] + mb * 2048);
+      const i32x4 hi = *(const i32x4*)(smem + slot * kHalfBytes + a_off[1] + mb * 2048);
+      a[mb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto read_b = [&](i32x8 (&b)[2], int slot) {
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+      const i32x4 lo = *(const i32x4*)(smem + slot * kHalfBytes + b_off[0] + nb * 2048);
+      const i32x4 hi = *(const i32x4*)(smem + slot * kHalfBytes + b_off[1] + nb * 2048);
+      b[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+  f32x4 acc[8][4];
+  i32x8 a[4], bp[2], bq[2];
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Half-tiles 0 and 1 landed.  A persistent workgroup has the previous tile's stores in the same counter
-    // behind the prologue's loads, and loads and stores complete in no fixed order with each other: wait for all.
-#ifdef GMD_GEMM_ABLATE
-    unsigned long long tl_top = 0, tl_ready = 0, tl_t0 = 0;
-    if constexpr (PERSIST && (ABL & 16)) tl_top = __builtin_amdgcn_s_memrealtime();
-#endif
-    if constexpr (PERSIST) wait_vmcnt<0>();
-    else wait_vmcnt<2 * (kAhead - 2)>();
-    GMD_PHASE_FENCE();
-    read_b(bp, 0);  // B-lo of K-tile 0
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef GMD_GEMM_ABLATE
-    if constexpr (PERSIST && (ABL & 16)) {
-      tl_ready = __builtin_amdgcn_s_memrealtime();
-      tl_t0 = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    if (wr == 1) { GMD_PHASE_FENCE(); }  // run the second wave row one barrier behind the first
+  };
 
-    for (int it = 0; it + 1 < npairs; it++) {
-      const int kt0 = 2 * it;
-      phase(std::integral_constant<int, 0>{}, F{}, kt0);
-      phase(std::integral_constant<int, 1>{}, F{}, kt0);
-      phase(std::integral_constant<int, 2>{}, F{}, kt0);
-      phase(std::integral_constant<int, 3>{}, F{}, kt0);
-      phase(std::integral_constant<int, 4>{}, F{}, kt0);
-      phase(std::integral_constant<int, 5>{}, F{}, kt0);
-      phase(std::integral_constant<int, 6>{}, F{}, kt0);
-      phase(std::integral_constant<int, 7>{}, F{}, kt0);
+  // One phase of a K-tile pair.  P: phase (0..7).  MODE: 0 inside a tile; 1 last pair of the workgroup's last tile
+  // (issue stops, waits shrink); 2 last pair of a tile with a successor (half-tiles 8.. are the successor's 0..);
+  // 3 first pair behind an epilogue (the stores may stay outstanding for five phases).
+  auto phase = [&](auto PH, auto MODEC, int kt0) {
+    constexpr int P = decltype(PH)::value, MODE = decltype(MODEC)::value;
+    constexpr int par = P >> 2, p = P & 3;
+    if constexpr (p == 0) read_a(a, par * 4 + 1);
+    else if constexpr (p == 1) read_b(par ? bp : bq, par * 4 + 2);
+    else if constexpr (p == 2) read_a(a, par * 4 + 3);
+    else if constexpr (!(MODE == 1 && P == 7)) read_b(par ? bp : bq, (par ^ 1) * 4 + 0);
+    constexpr int J = P + kAhead;
+    using KIND = std::integral_constant<int, (J & 3)>;
+    using PAR = std::integral_constant<int, ((J >> 2) & 1)>;
+    if constexpr (J < 8 || MODE == 0 || MODE == 3) {
+      issue(KIND{}, PAR{}, gA, gB, kt0 + (J >> 2));
+      wait_vmcnt<2 * (kAhead - 2) + ((MODE == 3 && P <= 4) ? kStores : 0)>();
+    } else if constexpr (MODE == 2) {
+      issue(KIND{}, PAR{}, nA, nB, (J >> 2) - 2);
+      wait_vmcnt<2 * (kAhead - 2)>();
+    } else if constexpr (P <= 5) {
+      wait_vmcnt<2 * (5 - P)>();  // nothing left to issue: half-tile P+2 must land, 7-(P+2) may still fly
     }
-    {
-      const int kt0 = 2 * (npairs - 1);
-      phase(std::integral_constant<int, 0>{}, T{}, kt0);
-      phase(std::integral_constant<int, 1>{}, T{}, kt0);
-      phase(std::integral_constant<int, 2>{}, T{}, kt0);
-      phase(std::integral_constant<int, 3>{}, T{}, kt0);
-      phase(std::integral_constant<int, 4>{}, T{}, kt0);
-      phase(std::integral_constant<int, 5>{}, T{}, kt0);
-      phase(std::integral_constant<int, 6>{}, T{}, kt0);
-      phase(std::integral_constant<int, 7>{}, T{}, kt0);
-    }
-    if (wr == 0) { GMD_PHASE_FENCE(); }  // the barrier the second wave row took up front
+    GMD_PHASE_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (p == 0) quadrant<0, 0, DT>(acc, a, par ? bq : bp);
+    else if constexpr (p == 1) quadrant<0, 2, DT>(acc, a, par ? bp : bq);
+    else if constexpr (p == 2) quadrant<4, 2, DT>(acc, a, par ? bp : bq);
+    else quadrant<4, 0, DT>(acc, a, par ? bq : bp);
+    __builtin_amdgcn_s_setprio(0);
+    GMD_PHASE_FENCE();
+  };
+  auto pair = [&](auto MODEC, int kt0) {
+    phase(std::integral_constant<int, 0>{}, MODEC, kt0);
+    phase(std::integral_constant<int, 1>{}, MODEC, kt0);
+    phase(std::integral_constant<int, 2>{}, MODEC, kt0);
+    phase(std::integral_constant<int, 3>{}, MODEC, kt0);
+    phase(std::integral_constant<int, 4>{}, MODEC, kt0);
+    phase(std::integral_constant<int, 5>{}, MODEC, kt0);
+    phase(std::integral_constant<int, 6>{}, MODEC, kt0);
+    phase(std::integral_constant<int, 7>{}, MODEC, kt0);
+  };
+  using M0 = std::integral_constant<int, 0>;
+  using M1 = std::integral_constant<int, 1>;
+  using M2 = std::integral_constant<int, 2>;
+  using M3 = std::integral_constant<int, 3>;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  const int npairs = (int)(row_bytes / BKB) >> 1;  // >= 2 (checked by the launcher)
+  // Prologue of the first tile: half-tiles 0..6 in flight, 0 and 1 landed, B-lo of K-tile 0 in registers.
+  issue(I0{}, I0{}, gA, gB, 0);
+  issue(I1{}, I0{}, gA, gB, 0);
+  issue(I2{}, I0{}, gA, gB, 0);
+  issue(I3{}, I0{}, gA, gB, 0);
+  issue(I0{}, I1{}, gA, gB, 1);
+  issue(I1{}, I1{}, gA, gB, 1);
+  issue(I2{}, I1{}, gA, gB, 1);
+  zero_acc();
+  wait_vmcnt<2 * (kAhead - 2)>();
+  GMD_PHASE_FENCE();
+  read_b(bp, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (wr == 1) { GMD_PHASE_FENCE(); }  // run the second wave row one barrier behind the first
+
+#ifdef GMD_GEMM_ABLATE
+  unsigned long long tl_top = 0, tl_t0 = 0;
+  if constexpr (ABL & 16) {
+    tl_top = __builtin_amdgcn_s_memrealtime();
+    tl_t0 = __builtin_amdgcn_s_memtime();
+  }
+#endif
+  pair(M0{}, 0);  // first pair of the first tile; every later tile's first pair runs at the bottom of the loop
+  for (;;) {
+    for (int it = 1; it + 1 < npairs; it++) pair(M0{}, 2 * it);
+    const int next = wgid + tile_step;
+    if (next >= chunk_end) break;
+    int ntm, ntn;
+    tile_of(next, tiles_m, tiles_n, &ntm, &ntn);
+    nA = A + (size_t)ntm * BM * row_bytes;
+    nB = B + (size_t)ntn * BN * row_bytes;
+    pair(M2{}, 2 * (npairs - 1));
 #ifdef GMD_GEMM_ABLATE
     if constexpr (ABL & 16) {
       asm volatile("s_nop 0" ::"v"(acc[7][3]));  // stamp behind the last MFMA's result
       const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
       if (threadIdx.x == 0 && wgid < kStampSlots) {
-        g_gemm_stamps[2 * wgid] = t1 - stamp_t0;
-        g_gemm_stamps[2 * wgid + 1] = r1 - stamp_r0;
-      }
-      stamp_t0 = t1;
-      stamp_r0 = r1;
-      if constexpr (PERSIST) {
-        if (threadIdx.x == 0 && wgid < kStampSlots) {
-          g_gemm_timeline[4 * wgid] = tl_top;
-          g_gemm_timeline[4 * wgid + 1] = tl_ready;
-          g_gemm_timeline[4 * wgid + 2] = r1;
-          g_gemm_timeline[4 * wgid + 3] = t1 - tl_t0;
-        }
+        g_gemm_timeline[4 * wgid] = tl_top;
+        g_gemm_timeline[4 * wgid + 1] = tl_top;
+        g_gemm_timeline[4 * wgid + 2] = r1;
+        g_gemm_timeline[4 * wgid + 3] = t1 - tl_t0;
       }
     }
 #endif
-
-    // Every wave is past the barrier behind the tile's last LDS read: the ring is free.  Start the next tile's
-    // fetches, then store this one while they fly.
-    const int m0 = tm * BM + wr * 128 + fr;
-    const int n0 = tn * BN + wc * 64 + fq * 4;
-    wgid += tile_step;
-    const bool more = wgid < chunk_end;
-    if (more) {
-      tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
-      gA = A + (size_t)((ABL & 8) ? 0 : tm) * BM * row_bytes;
-      gB = B + (size_t)((ABL & 8) ? 0 : tn) * BN * row_bytes;
-      issue_prologue();
+    store_acc<4, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 64, fq);
+    __builtin_amdgcn_sched_barrier(0);
+    zero_acc();
+    tm = ntm;
+    tn = ntn;
+    gA = nA;
+    gB = nB;
+    wgid = next;
+#ifdef GMD_GEMM_ABLATE
+    if constexpr (ABL & 16) {
+      tl_top = __builtin_amdgcn_s_memrealtime();
+      tl_t0 = __builtin_amdgcn_s_memtime();
     }
-#pragma unroll
-    for (int mb = 0; mb < 8; mb++)
-#pragma unroll
-      for (int nb = 0; nb < 4; nb++) {
-        bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
-        *(bf16x4*)(C + (size_t)(m0 + mb * 16) * N + n0 + nb * 16) = o;
-      }
-    if (!more) break;
+#endif
+    pair(M3{}, 0);
   }
+  pair(M1{}, 2 * (npairs - 1));
+  if (wr == 0) { GMD_PHASE_FENCE(); }  // the barrier the second wave row took up front
+#ifdef GMD_GEMM_ABLATE
+  if constexpr (ABL & 16) {
+    asm volatile("s_nop 0" ::"v"(acc[7][3]));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && wgid < kStampSlots) {
+      g_gemm_timeline[4 * wgid] = tl_top;
+      g_gemm_timeline[4 * wgid + 1] = tl_top;
+      g_gemm_timeline[4 * wgid + 2] = r1;
+      g_gemm_timeline[4 * wgid + 3] = t1 - tl_t0;
+    }
+  }
+#endif
+  store_acc<4, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 64, fq);
 }
 
 // ---- (2c) four waves, 128 x 128 of C each ---------------------------------------
@@ -580,7 +793,7 @@ __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x
 }
 #define W4_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
-template <int DT, int ABL = 0>  // ABL 16: clock stamps (ablation builds only)
+template <int DT, int ABL = 0, int EPI = 1>  // ABL 16: clock stamps (ablation builds only); EPI: see store_acc
 __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                              __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -737,15 +950,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   }
 #endif
 
-  const int m0 = tm * BM + wr * 128 + fr;
-  const int n0 = tn * BN + wc * 128 + fq * 4;
-#pragma unroll
-  for (int mb = 0; mb < 8; mb++)
-#pragma unroll
-    for (int nb = 0; nb < 8; nb++) {
-      bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
-      *(bf16x4*)(C + (size_t)(m0 + mb * 16) * N + n0 + nb * 16) = o;
-    }
+  store_acc<8, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
 }
 
 // ---- output checksum (integer, order-independent -> bitwise reproducible) ----
@@ -889,11 +1094,12 @@ double peak_flops_per_mfma(int dt) {
   }
 }
 
-// Which GEMM schedule runs: -1 = the faster pipeline for the dtype (default), 3 = eight waves of
-// 128 x 64 as a persistent grid (one workgroup per CU walking its tiles), 2 = four waves of
-// 128 x 128, 1 = eight waves of 128 x 64 with one workgroup per tile, 0 = the simple
-// double-buffered loop (kept as the A/B baseline and for odd K-tile counts).
+// Which GEMM schedule runs: -1 = the fastest for the dtype and shape (default); 0 = the simple double-buffered
+// loop (A/B baseline; also what odd K-tile counts run); 1 = eight waves of 128 x 64, one workgroup per tile;
+// 2 = four waves of 128 x 128; 3 = eight waves of 128 x 64 as one stream per CU over its tiles (gemm_ps_kernel);
+// 4 / 5 = schedule 1 with the narrow / the wide but cached epilogue (A/B references for store_acc).
 constexpr int kVariantUnset = -2;
+constexpr int kVariantMax = 5;
 int g_gemm_variant = kVariantUnset;
 
 int gemm_variant() {
@@ -918,128 +1124,75 @@ int persistent_grid() {
   return grid;
 }
 
+// Launch one instantiation with 128 KiB of dynamic LDS.  The opt-in attribute is per function and device; it is
+// set again whenever the (kernel, device) pair differs from the calling thread's previous launch.
+typedef void (*gemm_fn_t)(const char*, const char*, __bf16*, int, int, size_t);
+int launch_lds128(gemm_fn_t kfn, int grid, int threads, hipStream_t st, const void* a, const void* b, void* c, int m, int n,
+                  size_t row_bytes) {
+  thread_local gemm_fn_t last_fn = nullptr;
+  thread_local int last_dev = -1;
+  int dev = 0;
+  GMD_HIP(hipGetDevice(&dev));
+  if (last_fn != kfn || last_dev != dev) {
+    GMD_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    last_fn = kfn;
+    last_dev = dev;
+  }
+  kfn<<<grid, threads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+  GMD_HIP(hipGetLastError());
+  return GMD_OK;
+}
+
 template <int DT>
 int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t row_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    GMD_HIP(hipFuncSetAttribute((const void*)gemm_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    attr_set = true;
-  }
   const int grid = (m / BM) * (n / BN);
   const size_t ktiles = row_bytes / BKB;
+  const bool pairs = ktiles >= 2 && (ktiles & 1) == 0;                      // the pipelines walk K-tiles in pairs
+  const bool stream_ok = pairs && ktiles >= 4 && grid > persistent_grid();  // more tiles than CUs, two pairs per tile
+#define GMD_LAUNCH(KFN, GRID, THREADS) return launch_lds128(KFN, GRID, THREADS, st, a, b, c, m, n, row_bytes)
 #ifdef GMD_GEMM_ABLATE
-  // variants 10 + mask: timing-only builds of the pipeline with parts removed
-#define GMD_ABL_CASE(MASK)                                                                                             \
-  case 10 + MASK: {                                                                                                    \
-    static bool once = false;                                                                                          \
-    if (!once) {                                                                                                       \
-      GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  kLdsBytes));                                                                         \
-      once = true;                                                                                                     \
-    }                                                                                                                  \
-    gemm_pp_kernel<DT, MASK><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n,      \
-                                                                 row_bytes);                                           \
-    GMD_HIP(hipGetLastError());                                                                                        \
-    return GMD_OK;                                                                                                     \
-  }
-#define GMD_AHEAD_CASE(D)                                                                                              \
-  case 20 + D: {                                                                                                       \
-    static bool once = false;                                                                                          \
-    if (!once) {                                                                                                       \
-      GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  kLdsBytes));                                                                         \
-      once = true;                                                                                                     \
-    }                                                                                                                  \
-    gemm_pp_kernel<DT, 0, D><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n,      \
-                                                                 row_bytes);                                           \
-    GMD_HIP(hipGetLastError());                                                                                        \
-    return GMD_OK;                                                                                                     \
-  }
-#define GMD_MIX_CASE(ID, MASK, D)                                                                                      \
-  case ID: {                                                                                                           \
-    static bool once = false;                                                                                          \
-    if (!once) {                                                                                                       \
-      GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, MASK, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  kLdsBytes));                                                                         \
-      once = true;                                                                                                     \
-    }                                                                                                                  \
-    gemm_pp_kernel<DT, MASK, D><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n,   \
-                                                                    row_bytes);                                        \
-    GMD_HIP(hipGetLastError());                                                                                        \
-    return GMD_OK;                                                                                                     \
-  }
+  // Timing-only builds of the per-tile pipeline with parts removed (10 + mask), other issue distances (20 + d),
+  // clock stamps (41..46, 51) and the per-tile timeline of the streaming kernel (53).
   switch (gemm_variant()) {
-    GMD_AHEAD_CASE(5)
-    GMD_AHEAD_CASE(6)
-    GMD_AHEAD_CASE(7)
-    GMD_ABL_CASE(1)
-    GMD_ABL_CASE(2)
-    GMD_ABL_CASE(3)
-    GMD_ABL_CASE(4)
-    GMD_ABL_CASE(5)
-    GMD_ABL_CASE(6)
-    GMD_ABL_CASE(7)
-    GMD_ABL_CASE(8)   // 18: full pipeline, operands always L2-resident
-    GMD_ABL_CASE(13)  // 23: DMA only, operands always L2-resident
-    GMD_MIX_CASE(33, 5, 5)  // DMA only at issue distance 5
-    GMD_MIX_CASE(34, 5, 6)  // DMA only at issue distance 6
-    // 41..46: the same arms with clock stamps (read back with gmd_gemm_read_stamps)
-    GMD_MIX_CASE(41, 16, kAheadDefault)
-    GMD_MIX_CASE(42, 16 | 3, kAheadDefault)
-    GMD_MIX_CASE(43, 16 | 1, kAheadDefault)
-    GMD_MIX_CASE(44, 16 | 2, kAheadDefault)
-    GMD_MIX_CASE(45, 16 | 5, kAheadDefault)
-    GMD_MIX_CASE(46, 16 | 8, kAheadDefault)
-    case 51: {  // the four-wave kernel with clock stamps
-      static bool once = false;
-      if (!once) {
-        GMD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<DT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        once = true;
-      }
-      gemm_w4_kernel<DT, 16><<<grid, kThreadsW4, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
-      GMD_HIP(hipGetLastError());
-      return GMD_OK;
-    }
-    case 53: {  // the persistent eight-wave kernel with clock stamps and the per-tile timeline
-      static bool once = false;
-      if (!once) {
-        GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, 16, kAheadDefault, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        once = true;
-      }
-      gemm_pp_kernel<DT, 16, kAheadDefault, true><<<persistent_grid(), kThreads, kLdsBytes, st>>>(
-          (const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
-      GMD_HIP(hipGetLastError());
-      return GMD_OK;
-    }
+    case 25: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 5>), grid, kThreads);
+    case 26: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 6>), grid, kThreads);
+    case 27: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 7>), grid, kThreads);
+    case 11: GMD_LAUNCH((gemm_pp_kernel<DT, 1>), grid, kThreads);
+    case 12: GMD_LAUNCH((gemm_pp_kernel<DT, 2>), grid, kThreads);
+    case 13: GMD_LAUNCH((gemm_pp_kernel<DT, 3>), grid, kThreads);
+    case 14: GMD_LAUNCH((gemm_pp_kernel<DT, 4>), grid, kThreads);
+    case 15: GMD_LAUNCH((gemm_pp_kernel<DT, 5>), grid, kThreads);
+    case 16: GMD_LAUNCH((gemm_pp_kernel<DT, 6>), grid, kThreads);
+    case 17: GMD_LAUNCH((gemm_pp_kernel<DT, 7>), grid, kThreads);
+    case 18: GMD_LAUNCH((gemm_pp_kernel<DT, 8>), grid, kThreads);    // full pipeline, operands always L2-resident
+    case 23: GMD_LAUNCH((gemm_pp_kernel<DT, 13>), grid, kThreads);   // DMA only, operands always L2-resident
+    case 33: GMD_LAUNCH((gemm_pp_kernel<DT, 5, 5>), grid, kThreads);  // DMA only at issue distance 5
+    case 34: GMD_LAUNCH((gemm_pp_kernel<DT, 5, 6>), grid, kThreads);  // DMA only at issue distance 6
+    case 41: GMD_LAUNCH((gemm_pp_kernel<DT, 16>), grid, kThreads);
+    case 42: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 3>), grid, kThreads);
+    case 43: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 1>), grid, kThreads);
+    case 44: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 2>), grid, kThreads);
+    case 45: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 5>), grid, kThreads);
+    case 46: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 8>), grid, kThreads);
+    case 51: GMD_LAUNCH((gemm_w4_kernel<DT, 16>), grid, kThreadsW4);
+    case 53: GMD_LAUNCH((gemm_ps_kernel<DT, 1, 16>), persistent_grid(), kThreads);
     default: break;
   }
 #endif
-  // auto: the four-wave kernel is the faster one for MX-fp8 (+1.5-2.5 %), the eight-wave one for bf16 (+2 %)
-  const int variant = gemm_variant() < 0 ? (DT == GMD_DT_BF16 ? 1 : 2) : gemm_variant();
-  if (variant == 2 && ktiles >= 2 && (ktiles & 1) == 0) {
-    static bool w4_attr = false;
-    if (!w4_attr) {
-      GMD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-      w4_attr = true;
-    }
-    gemm_w4_kernel<DT><<<grid, kThreadsW4, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
-  } else if (variant == 3 && ktiles >= 2 && (ktiles & 1) == 0 && grid > persistent_grid()) {
-    static bool ps_attr = false;
-    if (!ps_attr) {
-      GMD_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<DT, 0, kAheadDefault, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-      ps_attr = true;
-    }
-    gemm_pp_kernel<DT, 0, kAheadDefault, true><<<persistent_grid(), kThreads, kLdsBytes, st>>>(
-        (const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
-  } else if (variant >= 1 && ktiles >= 2 && (ktiles & 1) == 0)
-    gemm_pp_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
-  else
-    gemm_kernel<DT><<<grid, kThreads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
-  GMD_HIP(hipGetLastError());
-  return GMD_OK;
+  // auto: bf16 runs the eight-wave kernels (the stream when there are more tiles than CUs), MX-fp8 the four-wave one
+  int variant = gemm_variant();
+  if (variant < 0 || variant > kVariantMax) variant = DT == GMD_DT_BF16 ? 3 : 2;
+  if (!pairs) variant = 0;
+  if (variant == 3 && !stream_ok) variant = 1;
+  switch (variant) {
+    case 1: GMD_LAUNCH((gemm_pp_kernel<DT>), grid, kThreads);
+    case 2: GMD_LAUNCH((gemm_w4_kernel<DT>), grid, kThreadsW4);
+    case 3: GMD_LAUNCH((gemm_ps_kernel<DT>), persistent_grid(), kThreads);
+    case 4: GMD_LAUNCH((gemm_pp_kernel<DT, 0, kAheadDefault, 0>), grid, kThreads);
+    case 5: GMD_LAUNCH((gemm_pp_kernel<DT, 0, kAheadDefault, 2>), grid, kThreads);
+    default: GMD_LAUNCH((gemm_kernel<DT>), grid, kThreads);
+  }
+#undef GMD_LAUNCH
 }
 
 }  // namespace
@@ -1054,7 +1207,7 @@ int gmd_gemm_set_variant(int variant) {
     return GMD_OK;
   }
 #endif
-  if (variant < -1 || variant > 3) return GMD_ERR_BADPARAM;
+  if (variant < -1 || variant > kVariantMax) return GMD_ERR_BADPARAM;
   g_gemm_variant = variant;
   return GMD_OK;
 }

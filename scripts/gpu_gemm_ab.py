@@ -1,6 +1,8 @@
 """A/B of the GEMM schedules on random data: numerics against fp32 matmul, then
-interleaved timing (variants 0 / 1 / 2 / 3 alternate inside one process) at several shapes,
-next to torch.matmul (hipBLASLt) for bf16.  Writes gpurun_out/gemm_ab.json."""
+interleaved timing (the variants alternate inside one process) at several shapes,
+next to torch.matmul (hipBLASLt) for bf16.  Writes gpurun_out/gemm_ab.json.
+GEMM_AB_VARIANTS (default 0,1,2,3,4,5), GEMM_AB_SIZES (default 4096,8192,16384) and GEMM_AB_PERSISTENT
+(variants that run as a persistent grid, default 3) choose what runs."""
 import json
 import os
 import sys
@@ -14,7 +16,9 @@ from k8s_gpu_monitor_amd.ops import diag  # noqa: E402
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 out = {"numerics": [], "timing": []}
-VARIANTS = (0, 1, 2, 3)
+VARIANTS = tuple(int(x) for x in os.environ.get("GEMM_AB_VARIANTS", "0,1,2,3,4,5").split(","))
+SIZES = tuple(int(x) for x in os.environ.get("GEMM_AB_SIZES", "4096,8192,16384").split(","))
+PERSISTENT = tuple(int(x) for x in os.environ.get("GEMM_AB_PERSISTENT", "3").split(","))
 
 
 def inputs(m, n, k, dtype, seed=0):
@@ -44,16 +48,16 @@ for dtype in ("bf16", "mxfp8"):
             ok = bool(torch.isfinite(c.float()).all()) and err < 6e-3
             ok_all &= ok
             out["numerics"].append({"dtype": dtype, "shape": [m, n, k], "variant": v, "rel_err": err, "ok": ok})
-        same = all(bool(torch.equal(res[0], res[v])) for v in VARIANTS)
+        same = all(bool(torch.equal(res[VARIANTS[0]], res[v])) for v in VARIANTS)
         ok_all &= same
         out["numerics"].append({"dtype": dtype, "shape": [m, n, k], "variants_bit_identical": same})
         print(dtype, (m, n, k), "err", [round(x["rel_err"], 5) for x in out["numerics"][-1 - len(VARIANTS):-1]], "identical", same,
               flush=True)
 
 # race screen: many launches of the pipeline variant must give one bit pattern
-for rv, dtype in [(v, d) for v in (1, 2, 3) for d in ("bf16", "mxfp8")]:
+for rv, dtype in [(v, d) for v in VARIANTS if v != 0 for d in ("bf16", "mxfp8")]:
     diag.gemm_set_variant(rv)
-    S = 8192 if rv == 3 else 4096  # the persistent grid needs more tiles than CUs
+    S = 8192 if rv in PERSISTENT else 4096  # the persistent grid needs more tiles than CUs
     a, b = inputs(S, S, 4096, dtype, seed=5)
     c = torch.empty(S, S, dtype=torch.bfloat16, device=dev)
     diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), S, S, 4096, stream)
@@ -85,25 +89,30 @@ def timeit(fn, n):
 
 
 for dtype in ("bf16", "mxfp8"):
-    for s in (4096, 8192, 16384):
+    for s in SIZES:
         a, b = inputs(s, s, s, dtype, seed=s)
         c = torch.empty(s, s, dtype=torch.bfloat16, device=dev)
         flops = 2.0 * s ** 3
         best = {v: 1e9 for v in VARIANTS + ("torch",)}
+        allms = {v: [] for v in VARIANTS + ("torch",)}
         n = 20 if s <= 8192 else 5
-        for rep in range(4):  # interleaved A/B
+        for rep in range(int(os.environ.get("GEMM_AB_REPS", "4"))):  # interleaved A/B
             for v in VARIANTS:
                 diag.gemm_set_variant(v)
                 ms = timeit(lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), s, s, s, stream), n)
                 best[v] = min(best[v], ms)
+                allms[v].append(ms)
             if dtype == "bf16":
                 bt = b.t()
                 ms = timeit(lambda: torch.matmul(a, bt), n)
                 best["torch"] = min(best["torch"], ms)
+                allms["torch"].append(ms)
         row = {"dtype": dtype, "size": s}
         row.update({f"tflops_v{v}": flops / best[v] / 1e9 for v in VARIANTS})
+        row.update({f"median_ms_v{v}": sorted(allms[v])[len(allms[v]) // 2] for v in VARIANTS})
         if dtype == "bf16":
             row["tflops_torch"] = flops / best["torch"] / 1e9
+            row["median_ms_torch"] = sorted(allms["torch"])[len(allms["torch"]) // 2]
         out["timing"].append(row)
         print(row, flush=True)
         del a, b, c

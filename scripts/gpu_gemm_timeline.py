@@ -1,4 +1,4 @@
-"""Where a persistent workgroup's time goes between tiles (make diag-ablate, variant 53):
+"""Where a persistent workgroup's time goes between tiles (make diag-ablate, variants 53..55, GEMM_TL_VARIANTS):
 per tile, real-time stamps at the top of the tile loop, when the first half-tiles (and the
 previous tile's stores) have landed, and after the last MFMA.  Prints, per tile round, the
 K-loop time, the wait at the top and the gap between the last MFMA of one tile and the top
@@ -27,12 +27,13 @@ out = []
 s = 8192
 ntiles = (s // 256) ** 2
 GRID = 256
-for dtype in ("bf16", "mxfp8"):
+for dtype, variant in [(d, v) for d in os.environ.get("GEMM_TL_DTYPES", "bf16,mxfp8").split(",")
+                       for v in (int(x) for x in os.environ.get("GEMM_TL_VARIANTS", "53").split(","))]:
     a = torch.randn(s, s, device=dev)
     b = torch.randn(s, s, device=dev)
     a, b = (a.bfloat16(), b.bfloat16()) if dtype == "bf16" else (a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn))
     c = torch.empty(s, s, dtype=torch.bfloat16, device=dev)
-    diag.gemm_set_variant(53)
+    diag.gemm_set_variant(variant)
     launch = lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), s, s, s, stream)
     for _ in range(5):
         launch()
@@ -53,7 +54,7 @@ for dtype in ("bf16", "mxfp8"):
     t_first = min(t[0] for t in tl)
     t_last = max(t[2] for t in tl)
     rounds = per_xcd // step
-    row = {"dtype": dtype, "ms_per_launch": round(ms, 4), "kernel_span_us_top_to_last_mfma": (t_last - t_first) / 100.0, "rounds": []}
+    row = {"dtype": dtype, "variant": variant, "ms_per_launch": round(ms, 4), "kernel_span_us_top_to_last_mfma": (t_last - t_first) / 100.0, "rounds": []}
     for r in range(rounds):
         ids = [x * per_xcd + r * step + j for x in range(8) for j in range(step)]
         kloop = [(tl[i][2] - tl[i][1]) / 100.0 for i in ids]

@@ -181,31 +181,32 @@ def test_gemm_matches_fp32_reference(diag, dev, dtype, shape):
 
 @pytest.mark.parametrize("dtype", ["bf16", "mxfp8"])
 def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
-    """The two pipelined schedules (eight waves x 128x64, four waves x 128x128 with AGPR accumulators)
-    and the simple double-buffered loop add the same products in the same order, so their outputs are
-    identical; repeated launches of a pipeline must not differ either (a race between LDS-DMA and
-    fragment reads, or a missed wait state around the hand-placed MFMAs, would show as run-to-run
-    differences).  K-tile counts of 2 (prologue + one pair), 4, 32 and 128 exercise the loop entry and
-    the surplus issue of the last pair; an odd number of K-tiles takes the fallback path."""
+    """The pipelined schedules (eight waves x 128x64 per tile, the same as one stream per CU over its
+    tiles, four waves x 128x128 with AGPR accumulators, the narrow and the cached epilogue) and the simple
+    double-buffered loop add the same products in the same order, so their outputs are identical; repeated
+    launches of a pipeline must not differ either (a race between LDS-DMA and fragment reads, a store
+    counted as a landed fetch, or a missed wait state around the hand-placed MFMAs, would show as
+    run-to-run differences).  K-tile counts of 2 (prologue + one pair), 4, 32 and 128 exercise the loop
+    entry and the surplus issue of the last pair; an odd number of K-tiles takes the fallback path."""
     kt = 128 if dtype == "mxfp8" else 64  # elements per 128-byte K-tile
     try:
         for (m, n, k) in [(512, 512, 2 * kt), (256, 512, 4 * kt), (512, 512, 32 * kt), (1024, 768, 128 * kt), (256, 256, 3 * kt),
-                          (4352, 4352, 4 * kt)]:  # 289 tiles: more than CUs, so variant 3 runs as a persistent grid
+                          (4352, 4352, 4 * kt), (4352, 4608, 10 * kt)]:  # 289 / 306 tiles: more than CUs, variant 3 streams
             a, b = _gemm_inputs(dev, m, n, k, dtype, seed=k)
             outs = {}
-            for variant in (0, 1, 2, 3, -1):
+            for variant in (0, 1, 2, 3, 4, 5, -1):
                 diag.gemm_set_variant(variant)
                 c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
                 diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, _stream())
                 torch.cuda.synchronize()
                 outs[variant] = c
-                if variant in (1, 2, 3):
+                if variant in (1, 2, 3):  # 4 and 5 differ from 1 in the epilogue only
                     c2 = torch.empty_like(c)
                     for _ in range(20):
                         diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c2.data_ptr(), m, n, k, _stream())
                     torch.cuda.synchronize()
                     assert torch.equal(c2, c), (variant, m, n, k)
-            for variant in (1, 2, 3, -1):
+            for variant in (1, 2, 3, 4, 5, -1):
                 assert torch.equal(outs[0], outs[variant]), (variant, m, n, k)
         with pytest.raises(diag.DiagError):
             diag.gemm_set_variant(9)
