@@ -138,6 +138,12 @@ class GpuKernels:
         self.A8 = torch.empty(D, D, dtype=torch.float32, device=dev).normal_(generator=g).to(torch.float8_e4m3fn)
         self.B8 = torch.empty(D, D, dtype=torch.float32, device=dev).normal_(generator=g).to(torch.float8_e4m3fn)
         self.C8 = torch.empty(D, D, dtype=torch.bfloat16, device=dev)
+        # MX block scales: one E8M0 byte per row and 32 k, 2^-3 .. 2^3, in the packed layout the kernel reads
+        self.SA8, self.SB8 = (torch.empty(D, D // 32, dtype=torch.uint8, device=dev) for _ in range(2))
+        for packed in (self.SA8, self.SB8):
+            nat = torch.randint(124, 131, (D, D // 32), dtype=torch.uint8, device=dev, generator=g)
+            diag.mx_pack_scales(nat.data_ptr(), packed.data_ptr(), D, D, self.sptr)
+        torch.cuda.synchronize()
 
     def event(self):
         return self.torch.cuda.Event(enable_timing=True)
@@ -181,7 +187,8 @@ class GpuKernels:
     def gemm_mxfp8(self):
         D = self.sz.gemm_dim
         for _ in range(self.G):
-            self.diag.gemm_launch("mxfp8", self.A8.data_ptr(), self.B8.data_ptr(), self.C8.data_ptr(), D, D, D, self.sptr)
+            self.diag.gemm_launch("mxfp8", self.A8.data_ptr(), self.B8.data_ptr(), self.C8.data_ptr(), D, D, D, self.sptr,
+                                  scale_a=self.SA8.data_ptr(), scale_b=self.SB8.data_ptr())
 
 
 class DryKernels:

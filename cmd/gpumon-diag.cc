@@ -6,7 +6,7 @@
 //   gpumon-diag hbm    [-g GPU] [--bytes N] [--iters N] [--kernel NAME|all] [--min-tbps X]
 //   gpumon-diag memtest[-g GPU] [--bytes N | --fraction F] [--patterns a,b] [--passes N]
 //   gpumon-diag mfma   [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]
-//   gpumon-diag gemm   [-g GPU] [--dtype bf16|mxfp8|fp8] [--m M --n N --k K] [--seconds S] [--no-telemetry] [--mfma-counters]
+//   gpumon-diag gemm   [-g GPU] [--dtype bf16|fp8|mxfp8] [--m M --n N --k K] [--seconds S] [--no-telemetry] [--mfma-counters]
 //   gpumon-diag rccl   [--gpus 0,1,..] [--ops a,b] [--min-bytes N] [--max-bytes N] [--scaling]
 //   gpumon-diag p2p    [--gpus 0,1,..] [--bytes N]
 //   gpumon-diag run -r 1|2|3 [-g GPU]      graded suites: quick / medium / long
@@ -513,9 +513,10 @@ int cmd_gemm(const Args& a, Report& r) {
       end_watch();
       return 2;
     }
-    r.text("GEMM stress %s %dx%dx%d on GPU %d: %.1f TFLOP/s (best %.1f), %llu launches in %.1f s, sdc mismatches %llu, check %s\n",
+    r.text("GEMM stress %s %dx%dx%d on GPU %d: %.1f TFLOP/s (best %.1f), %llu launches in %.1f s, sdc mismatches %llu, "
+           "max rel err vs fp32 reference %.2e, check %s\n",
            name.c_str(), m, n, k, gpu, g.tflops, g.tflops_best, (unsigned long long)g.launches, g.seconds,
-           (unsigned long long)g.sdc_mismatches, g.verified > 0 ? "ok" : g.verified < 0 ? "WRONG" : "skipped");
+           (unsigned long long)g.sdc_mismatches, g.max_rel_err, g.verified > 0 ? "ok" : g.verified < 0 ? "WRONG" : "skipped");
     obj += std::string(any ? "," : "") + "\"" + name + "\":{\"tflops\":" + jnum(g.tflops) + ",\"tflops_best\":" +
            jnum(g.tflops_best) + ",\"launches\":" + std::to_string(g.launches) + ",\"sdc_mismatches\":" +
            std::to_string(g.sdc_mismatches) + ",\"max_rel_err\":" + jnum(g.max_rel_err) + ",\"verified\":" +
@@ -532,7 +533,8 @@ int cmd_gemm(const Args& a, Report& r) {
     }
     obj += "}";
     any = true;
-    if (g.verified < 0) r.fail("GEMM %s result does not match the reference", name.c_str());
+    if (g.verified < 0 && !g.sdc_mismatches)
+      r.fail("GEMM %s: sampled entries differ from the fp32 reference (max relative error %.3g, tolerance 4e-3)", name.c_str(), g.max_rel_err);
     if (g.sdc_mismatches) r.fail("GEMM %s: %llu launches changed their checksum (silent data corruption)", name.c_str(), (unsigned long long)g.sdc_mismatches);
     if (floor_tf > 0 && g.tflops < floor_tf) r.fail("GEMM %s %.1f TFLOP/s is under the %.1f floor", name.c_str(), g.tflops, floor_tf);
   }

@@ -147,19 +147,30 @@ typedef struct {
 
 /* Matrix-pipe peak: MFMAs on register-resident operands, no memory traffic. */
 GMD_API int gmd_mfma_peak(int device, int dtype, double seconds, gmd_mfma_result_t* out);
-/* GEMM stress: C[M,N] = A[M,K] * B[N,K]^T on random data for `seconds` (>= 1 launch);
- * every launch's output checksum is compared with the first one (silent-data-corruption check). */
+/* GEMM stress: C[M,N] = A[M,K] * B[N,K]^T on random data for `seconds` (>= 1 launch).  With `verify`, the
+ * first launch is compared with an independent reference (4096 sampled entries of C against full-K dot
+ * products computed by a separate kernel in double precision: max_rel_err, tolerance 4e-3 of |ref| + rms) and
+ * every later launch's output checksum with the first one's (silent-data-corruption check). */
 GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, int verify,
                             gmd_mfma_result_t* out);
-/* One GEMM on caller memory.  A: [M,K] row-major, B: [N,K] row-major (i.e. B^T), C: [M,N] row-major.
- * bf16: A,B bf16, C bf16.  fp8: A,B OCP e4m3, C bf16.  M,N multiples of 256; K multiple of 64 (bf16) / 128 (fp8). */
+/* One GEMM on caller memory.  A: [M,K] row-major, B: [N,K] row-major (i.e. B^T), C: [M,N] row-major bf16.
+ * GMD_DT_BF16: A, B bf16.  GMD_DT_FP8: A, B OCP e4m3, unscaled (mfma_f32_16x16x32_fp8_fp8).
+ * M, N multiples of 256; K a multiple of 64 (bf16) / 128 (fp8).  GMD_DT_MXFP8 needs scales: gmd_gemm_launch_mx. */
 GMD_API int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream);
+/* OCP MX-fp8 GEMM: e4m3 elements with one E8M0 scale (2^(e-127)) per row and 32 consecutive k, on the
+ * block-scaled MFMA (mfma_scale_f32_16x16x128_f8f6f4).  The scale tensors are in the packed form that
+ * gmd_mx_pack_scales produces from row-major uint8 [rows][K/32] (rows a multiple of 64, K of 128; the packed
+ * tensor has the same number of bytes and must be 4-byte aligned). */
+GMD_API int gmd_gemm_launch_mx(const void* a, const void* b, const void* scale_a_packed, const void* scale_b_packed, void* c,
+                               int m, int n, int k, void* hip_stream);
+GMD_API int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int rows, int k, void* hip_stream);
 
-/* GEMM schedule: -1 = the faster pipeline for the dtype (default: eight waves for bf16, four
- * for MX-fp8), 1 = eight waves x 128x64 phase-interleaved, 2 = four waves x 128x128 with the
- * accumulators in AGPRs (both need an even number of 128-byte K-tiles, otherwise the launch
- * falls back), 0 = simple double-buffered loop.  All three give bit-identical results.
- * Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
+/* GEMM schedule: -1 = the fastest for the dtype and shape (default); 0 = simple double-buffered loop;
+ * 1 = eight waves x 128x64, one workgroup per tile; 2 = four waves x 128x128 with the accumulators in AGPRs;
+ * 3 = eight waves x 128x64 as one stream per CU over its tiles (needs more tiles than CUs and >= 4 K-tiles);
+ * 4 / 5 = schedule 1 with the narrow / the cached epilogue (A/B references).  The pipelines need an even
+ * number of 128-byte K-tiles, otherwise the launch falls back to 0.  MX-fp8 runs 2 (or 0).  All schedules give
+ * bit-identical results.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
 
 /* Timing-only ablation builds (make diag-ablate): per-workgroup pairs (shader-clock ticks,

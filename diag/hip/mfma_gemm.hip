@@ -18,8 +18,8 @@
 //     XOR-permuted:  chunk' = chunk ^ f(row & 7).  ds_read_b128 is serviced in
 //     four 16-lane groups and each group of an MFMA fragment read touches all
 //     16 rows once with two chunk values, so f is chosen to make the 16 slots
-//     of every group distinct: f = 2*((row&7)>>1) for bf16 (chunk pairs {c,c^1}),
-//     f = ((row&7)>>1 & 1) | ((row&7)>>2)<<2 for MX-fp8 (pairs {c,c^2}).
+//     of every group distinct: f = 2*((row&7)>>1) (a group's lanes read chunks
+//     {c, c^1} over its 16 rows).
 //     Conflict-free reads, fully coalesced fetches, linear DMA destination;
 //     the permutation lives in the per-lane SOURCE address and in the read
 //     address, never in the DMA destination.
@@ -32,6 +32,21 @@
 //     Workgroup ids are remapped so the tiles one XCD works on are contiguous
 //     (its private L2 then holds a few A row-panels and the B column panels it
 //     re-reads) with the bijective form that is valid for any grid size.
+//
+//     Data types.  bf16: mfma_f32_16x16x32_bf16, one per 16-byte fragment read.
+//     fp8 (OCP e4m3, unscaled): mfma_f32_16x16x32_fp8_fp8, two per 16-byte read —
+//     the low and the high 8 bytes; which k a lane's bytes stand for only has to be
+//     the same in both operands, so the bf16 image and swizzle serve unchanged.
+//     MX-fp8: mfma_scale_f32_16x16x128_f8f6f4 with one E8M0 scale per row and 32
+//     consecutive k (the OCP MX block).  Lane (fr, fq) holds k 16*fq .. +15 in operand
+//     registers 0-3 and k 64 + 16*fq .. +15 in registers 4-7 — the same two 16-byte
+//     chunks a bf16 lane reads — and supplies the scale of row fr, block fq (k 32*fq ..
+//     +31; measured with one-hot scales and operands, scripts/gpu_mx_probe.py).
+//     Scales arrive "packed": per 64 rows and per K-tile one 256-byte unit
+//     whose dword fq*16 + fr holds, in byte mb, the scale of row 16*mb + fr, block
+//     fq.  A wave reads the unit with one dword per lane and selects the byte of
+//     the 16-row block with the instruction's op_sel field: no shifts, no masks.
+//     gmd_mx_pack_scales builds the packed form from a row-major [rows][K/32] one.
 #include <hip/hip_bf16.h>
 
 #include <chrono>
@@ -51,6 +66,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef long i64x1;
 
+// One unscaled fp8 MFMA on the low (H = 0) or high (H = 1) 8 bytes of a 16-byte fragment read.
+template <int H>
+__device__ __forceinline__ f32x4 mfma_fp8_half(const i32x4& b, const i32x4& a, const f32x4& c) {
+  const long bl = ((long)(unsigned)b[2 * H + 1] << 32) | (unsigned)b[2 * H];
+  const long al = ((long)(unsigned)a[2 * H + 1] << 32) | (unsigned)a[2 * H];
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bl, al, c, 0, 0, 0);
+}
+// Packed MX scale units: 64 dwords per (64-row group, K-tile).
+constexpr int kScaleUnitDwords = 64;
+
 constexpr int BM = 256, BN = 256, BKB = 128;  // K-step in BYTES per row
 constexpr int kThreads = 512;
 constexpr int kTileBytes = BM * BKB;           // 32 KiB per operand per buffer
@@ -60,8 +85,7 @@ constexpr int kLdsBytes = 2 * kBufBytes;       // double buffered: 128 KiB
 template <int DT>
 __device__ __forceinline__ int chunk_swizzle(int row_in_piece) {
   const int q = row_in_piece >> 1;  // 0..3
-  if constexpr (DT == GMD_DT_BF16) return q << 1;
-  else return (q & 1) | ((q >> 1) << 2);
+  return q << 1;  // the same for every data type: all of them read chunk pairs {c, c + 4} (see the head of the file)
 }
 
 // Byte offset of 16-byte chunk `ch` (0..7) of tile row `row` inside one operand tile.
@@ -87,9 +111,47 @@ __device__ __forceinline__ void stage(const char* __restrict__ g, size_t row_byt
   }
 }
 
+// Store a wave's accumulators as bf16.  Each lane holds four consecutive N elements (8 bytes) of one row per
+// 16 x 16 block; EPI = 0 stores them as they are (32 stores of 8 bytes per lane).  EPI = 1 first exchanges
+// halves between neighbouring 16-lane rows of two adjacent blocks (v_permlane16_swap: odd rows of the first
+// operand <-> even rows of the second), after which every lane holds eight consecutive elements of one block and
+// stores 16 bytes: half the store instructions for the same bytes and addresses.  EPI = 1 also marks the stores
+// non-temporal (C is never read back); EPI = 2 leaves them cached.
+template <int NBLK, int EPI>
+__device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* __restrict__ C, size_t ldc, int m0, int nbase,
+                                          int fq) {
+  if constexpr (EPI == 0) {
+#pragma unroll
+    for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+      for (int nb = 0; nb < NBLK; nb++) {
+        bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
+        *(bf16x4*)(C + (size_t)(m0 + mb * 16) * ldc + nbase + fq * 4 + nb * 16) = o;
+      }
+  } else {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int col = nbase + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+    for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+      for (int nb = 0; nb < NBLK; nb += 2) {
+        u32x2 x = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb], bf16x4));
+        u32x2 y = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb + 1], bf16x4));
+        const u32x2 r0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+        const u32x2 r1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+        const u32x4 o = u32x4{r0.x, r1.x, r0.y, r1.y};
+        u32x4* dst = (u32x4*)(C + (size_t)(m0 + mb * 16) * ldc + col + nb * 16);
+        if constexpr (EPI == 1) __builtin_nontemporal_store(o, dst);
+        else *dst = o;
+      }
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restrict__ A, const char* __restrict__ B,
-                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes,
+                                                           const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,26 +172,26 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restric
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Per-lane fragment read offsets.  A fragment of 16 rows x 32 k-bytes... :
-  //   bf16 : lane reads row (lane&15), chunk ks*4 + (lane>>4)            -> one b128 per k-substep (2 per K-step)
-  //   mxfp8: lane reads row (lane&15), chunks 2*(lane>>4) + {0,1}        -> two b128 for the single K=128 MFMA
+  //   lane reads row (lane&15), chunks (lane>>4) and 4 + (lane>>4): bf16 / fp8 one k-substep each, MX-fp8 the two
+  //   halves of the single K=128 operand (registers 0-3: k 16*fq.., registers 4-7: k 64 + 16*fq..)
   const int fr = lane & 15, fq = lane >> 4;
   int a_off[2], b_off[2];
   {
     const int arow = wr * 128 + fr, brow = wc * 64 + fr;
-    if constexpr (DT == GMD_DT_BF16) {
-      a_off[0] = lds_off<DT>(arow, fq);
-      a_off[1] = lds_off<DT>(arow, 4 + fq);
-      b_off[0] = lds_off<DT>(brow, fq);
-      b_off[1] = lds_off<DT>(brow, 4 + fq);
-    } else {
-      a_off[0] = lds_off<DT>(arow, 2 * fq);
-      a_off[1] = lds_off<DT>(arow, 2 * fq + 1);
-      b_off[0] = lds_off<DT>(brow, 2 * fq);
-      b_off[1] = lds_off<DT>(brow, 2 * fq + 1);
-    }
+    a_off[0] = lds_off<DT>(arow, fq);
+    a_off[1] = lds_off<DT>(arow, 4 + fq);
+    b_off[0] = lds_off<DT>(brow, fq);
+    b_off[1] = lds_off<DT>(brow, 4 + fq);
   }
 
   const int nt = (int)(row_bytes / BKB);
+  // MX: this wave's scale units are those of A row groups 4*tm + 2*wr + {0, 1} and B row group 4*tn + wc.
+  const uint32_t* sa0 = nullptr;
+  const uint32_t* sb0 = nullptr;
+  if constexpr (DT == GMD_DT_MXFP8) {
+    sa0 = SA + ((size_t)(4 * tm + 2 * wr) * nt) * kScaleUnitDwords + lane;
+    sb0 = SB + ((size_t)(4 * tn + wc) * nt) * kScaleUnitDwords + lane;
+  }
   stage<DT>(gA, row_bytes, 0, smem, wave, lane);
   stage<DT>(gB, row_bytes, 0, smem + kTileBytes, wave, lane);
   __syncthreads();  // with LDS-DMA in flight this also waits vmcnt(0)
@@ -143,24 +205,33 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restric
     }
     const char* la = cur;
     const char* lb = cur + kTileBytes;
-    if constexpr (DT == GMD_DT_BF16) {
+    if constexpr (DT != GMD_DT_MXFP8) {
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
-        bf16x8 af[8], bfr[4];
+        i32x4 af[8], bfr[4];
 #pragma unroll
-        for (int nb = 0; nb < 4; nb++) bfr[nb] = *(const bf16x8*)(lb + b_off[ks] + nb * 2048);
+        for (int nb = 0; nb < 4; nb++) bfr[nb] = *(const i32x4*)(lb + b_off[ks] + nb * 2048);
 #pragma unroll
-        for (int mb = 0; mb < 8; mb++) af[mb] = *(const bf16x8*)(la + a_off[ks] + mb * 2048);
+        for (int mb = 0; mb < 8; mb++) af[mb] = *(const i32x4*)(la + a_off[ks] + mb * 2048);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mb = 0; mb < 8; mb++)
 #pragma unroll
-          for (int nb = 0; nb < 4; nb++)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nb], af[mb], acc[mb][nb], 0, 0, 0);
+          for (int nb = 0; nb < 4; nb++) {
+            if constexpr (DT == GMD_DT_BF16) {
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[nb]),
+                                                                    __builtin_bit_cast(bf16x8, af[mb]), acc[mb][nb], 0, 0, 0);
+            } else {
+              acc[mb][nb] = mfma_fp8_half<0>(bfr[nb], af[mb], acc[mb][nb]);
+              acc[mb][nb] = mfma_fp8_half<1>(bfr[nb], af[mb], acc[mb][nb]);
+            }
+          }
         __builtin_amdgcn_s_setprio(0);
       }
     } else {
-      // MX-scaled fp8: one K=128 MFMA per tile pair, unit scales (E8M0 127 = 2^0).
+      // MX-scaled fp8: one K=128 MFMA per tile pair; the scale byte of a 16-row block is picked by op_sel.
+      const int sa_lo = (int)sa0[(size_t)t * kScaleUnitDwords], sa_hi = (int)sa0[((size_t)nt + t) * kScaleUnitDwords];
+      const int sb = (int)sb0[(size_t)t * kScaleUnitDwords];
       i32x8 bfr[4];
 #pragma unroll
       for (int nb = 0; nb < 4; nb++) {
@@ -171,25 +242,29 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restric
       for (int mb = 0; mb < 8; mb++) {
         i32x4 lo = *(const i32x4*)(la + a_off[0] + mb * 2048), hi = *(const i32x4*)(la + a_off[1] + mb * 2048);
         i32x8 af = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const int sa = mb < 4 ? sa_lo : sa_hi;
 #pragma unroll
-        for (int nb = 0; nb < 4; nb++)
-          acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[nb], af, acc[mb][nb], 0, 0, 0, 0x7f7f7f7f, 0,
-                                                                         0x7f7f7f7f);
+        for (int nb = 0; nb < 4; nb++) {
+          // operands are swapped (B first): the first scale belongs to B's block nb, the second to A's block mb & 3
+          switch ((mb & 3) * 4 + nb) {
+#define GMD_MX_CASE(MBQ, NBQ)                                                                                              \
+  case MBQ * 4 + NBQ:                                                                                                      \
+    acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[nb], af, acc[mb][nb], 0, 0, NBQ, sb, MBQ, sa);     \
+    break;
+            GMD_MX_CASE(0, 0) GMD_MX_CASE(0, 1) GMD_MX_CASE(0, 2) GMD_MX_CASE(0, 3)
+            GMD_MX_CASE(1, 0) GMD_MX_CASE(1, 1) GMD_MX_CASE(1, 2) GMD_MX_CASE(1, 3)
+            GMD_MX_CASE(2, 0) GMD_MX_CASE(2, 1) GMD_MX_CASE(2, 2) GMD_MX_CASE(2, 3)
+            GMD_MX_CASE(3, 0) GMD_MX_CASE(3, 1) GMD_MX_CASE(3, 2) GMD_MX_CASE(3, 3)
+#undef GMD_MX_CASE
+          }
+        }
       }
     }
     __syncthreads();  // next buffer landed (vmcnt(0)) and everyone is done reading this one
   }
 
   // Epilogue: lane holds C[m][n..n+3] for m = .. + (lane&15), n = .. + (lane>>4)*4.
-  const int m0 = tm * BM + wr * 128 + fr;
-  const int n0 = tn * BN + wc * 64 + fq * 4;
-#pragma unroll
-  for (int mb = 0; mb < 8; mb++)
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) {
-      bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
-      *(bf16x4*)(C + (size_t)(m0 + mb * 16) * N + n0 + nb * 16) = o;
-    }
+  store_acc<4, 1>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 64, fq);
 }
 
 // ---- (2b) the same GEMM as a phase-interleaved pipeline -------------------------
@@ -254,49 +329,19 @@ __device__ __forceinline__ void quadrant(f32x4 (&acc)[8][4], const i32x8 (&a)[4]
               __builtin_bit_cast(bf16x8, bh), __builtin_bit_cast(bf16x8, ah), acc[MB0 + mb][NB0 + nb], 0, 0, 0);
         }
   } else {
+    static_assert(DT == GMD_DT_FP8, "the eight-wave pipelines run bf16 and unscaled fp8; MX-fp8 runs gemm_w4_kernel");
 #pragma unroll
-    for (int mb = 0; mb < 4; mb++)
+    for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-      for (int nb = 0; nb < 2; nb++)
-        acc[MB0 + mb][NB0 + nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[nb], a[mb], acc[MB0 + mb][NB0 + nb], 0, 0, 0,
-                                                                                 0x7f7f7f7f, 0, 0x7f7f7f7f);
-  }
-}
-
-// Store a wave's accumulators as bf16.  Each lane holds four consecutive N elements (8 bytes) of one row per
-// 16 x 16 block; EPI = 0 stores them as they are (32 stores of 8 bytes per lane).  EPI = 1 first exchanges
-// halves between neighbouring 16-lane rows of two adjacent blocks (v_permlane16_swap: odd rows of the first
-// operand <-> even rows of the second), after which every lane holds eight consecutive elements of one block and
-// stores 16 bytes: half the store instructions for the same bytes and addresses.  EPI = 1 also marks the stores
-// non-temporal (C is never read back); EPI = 2 leaves them cached.
-template <int NBLK, int EPI>
-__device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* __restrict__ C, size_t ldc, int m0, int nbase,
-                                          int fq) {
-  if constexpr (EPI == 0) {
+      for (int h = 0; h < 2; h++)
 #pragma unroll
-    for (int mb = 0; mb < 8; mb++)
+        for (int mb = 0; mb < 4; mb++)
 #pragma unroll
-      for (int nb = 0; nb < NBLK; nb++) {
-        bf16x4 o = __builtin_convertvector(acc[mb][nb], bf16x4);
-        *(bf16x4*)(C + (size_t)(m0 + mb * 16) * ldc + nbase + fq * 4 + nb * 16) = o;
-      }
-  } else {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const int col = nbase + (fq & 1) * 16 + (fq >> 1) * 8;
-#pragma unroll
-    for (int mb = 0; mb < 8; mb++)
-#pragma unroll
-      for (int nb = 0; nb < NBLK; nb += 2) {
-        u32x2 x = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb], bf16x4));
-        u32x2 y = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb + 1], bf16x4));
-        const u32x2 r0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
-        const u32x2 r1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
-        const u32x4 o = u32x4{r0.x, r1.x, r0.y, r1.y};
-        u32x4* dst = (u32x4*)(C + (size_t)(m0 + mb * 16) * ldc + col + nb * 16);
-        if constexpr (EPI == 1) __builtin_nontemporal_store(o, dst);
-        else *dst = o;
-      }
+          for (int nb = 0; nb < 2; nb++) {
+            const i32x4 bh = ks ? __builtin_shufflevector(b[nb], b[nb], 4, 5, 6, 7) : __builtin_shufflevector(b[nb], b[nb], 0, 1, 2, 3);
+            const i32x4 ah = ks ? __builtin_shufflevector(a[mb], a[mb], 4, 5, 6, 7) : __builtin_shufflevector(a[mb], a[mb], 0, 1, 2, 3);
+            acc[MB0 + mb][NB0 + nb] = h ? mfma_fp8_half<1>(bh, ah, acc[MB0 + mb][NB0 + nb]) : mfma_fp8_half<0>(bh, ah, acc[MB0 + mb][NB0 + nb]);
+          }
   }
 }
 
@@ -326,7 +371,8 @@ __device__ unsigned long long g_gemm_timeline[4 * kStampSlots];
 // EPI: see store_acc.
 template <int DT, int ABL = 0, int AHEAD = kAheadDefault, int EPI = 1>
 __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restrict__ A, const char* __restrict__ B,
-                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes,
+                                                           const uint32_t*, const uint32_t*) {  // no scales: bf16 / fp8 only
   constexpr int kAhead = AHEAD;  // half-tiles issued ahead of the running phase; kAhead - 2 of them are in flight
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -384,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
   int a_off[2], b_off[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
-    const int ch = DT == GMD_DT_BF16 ? ks * 4 + fq : 2 * fq + ks;
+    const int ch = ks * 4 + fq;
     a_off[ks] = lds_off<DT>(wr * 64 + fr, ch);
     b_off[ks] = lds_off<DT>(wc * 32 + fr, ch);
   }
@@ -537,7 +583,8 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
 // row runs its MFMAs.
 template <int DT, int EPI = 1, int ABL = 0>  // ABL 16: clock stamps and per-tile timeline (ablation builds only)
 __global__ __launch_bounds__(kThreads) void gemm_ps_kernel(const char* __restrict__ A, const char* __restrict__ B,
-                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+                                                           __bf16* __restrict__ C, int M, int N, size_t row_bytes,
+                                                           const uint32_t*, const uint32_t*) {  // no scales: bf16 / fp8 only
   constexpr int kAhead = kAheadDefault;
   static_assert(kAhead == 7, "the mode tables below are written for an issue distance of seven half-tiles");
   constexpr int kStores = EPI ? 16 : 32;  // store instructions per wave of one tile (store_acc)
@@ -588,7 +635,7 @@ __global__ __launch_bounds__(kThreads) void gemm_ps_kernel(const char* __restric
   int a_off[2], b_off[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
-    const int ch = DT == GMD_DT_BF16 ? ks * 4 + fq : 2 * fq + ks;
+    const int ch = ks * 4 + fq;
     a_off[ks] = lds_off<DT>(wr * 64 + fr, ch);
     b_off[ks] = lds_off<DT>(wc * 32 + fr, ch);
   }
@@ -779,23 +826,52 @@ constexpr int kAheadW4 = 8;
 // with the builtin, hipcc (ROCm 7.2) spreads them over VGPRs and AGPRs and moves them
 // about with ~2 v_accvgpr copies per MFMA; the "+a" constraint pins each one to its
 // AGPR quad.  An MFMA whose C operand is the previous MFMA's whole result needs no wait
-// states; the epilogue's reads come after W4_DRAIN.  `unit` holds 0x7f7f7f7f: E8M0
-// scale 2^0 for all four blocks of both operands.
-template <int DT>
-__device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x8& b, int ks, int unit) {
+// states; the epilogue's reads come after W4_DRAIN.
+// `sub`: bf16 k-substep (0 / 1); fp8 k-substep * 2 + half (0..3); unused for MX-fp8, whose scale dwords
+// sa / sb hold four E8M0 bytes each and whose op_sel fields pick byte MBQ (A, second operand) and NBQ (B, first).
+template <int DT, int MBQ, int NBQ>
+__device__ __forceinline__ void mfma_step_t(f32x4& acc, const i32x8& a, const i32x8& b, int sub, int sa, int sb) {
   if constexpr (DT == GMD_DT_BF16) {
-    const i32x4 bh = ks ? __builtin_shufflevector(b, b, 4, 5, 6, 7) : __builtin_shufflevector(b, b, 0, 1, 2, 3);
-    const i32x4 ah = ks ? __builtin_shufflevector(a, a, 4, 5, 6, 7) : __builtin_shufflevector(a, a, 0, 1, 2, 3);
+    const i32x4 bh = sub ? __builtin_shufflevector(b, b, 4, 5, 6, 7) : __builtin_shufflevector(b, b, 0, 1, 2, 3);
+    const i32x4 ah = sub ? __builtin_shufflevector(a, a, 4, 5, 6, 7) : __builtin_shufflevector(a, a, 0, 1, 2, 3);
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(bh), "v"(ah));
+  } else if constexpr (DT == GMD_DT_FP8) {
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const i32x2 bh = sub == 0 ? __builtin_shufflevector(b, b, 0, 1) : sub == 1 ? __builtin_shufflevector(b, b, 2, 3)
+                     : sub == 2 ? __builtin_shufflevector(b, b, 4, 5) : __builtin_shufflevector(b, b, 6, 7);
+    const i32x2 ah = sub == 0 ? __builtin_shufflevector(a, a, 0, 1) : sub == 1 ? __builtin_shufflevector(a, a, 2, 3)
+                     : sub == 2 ? __builtin_shufflevector(a, a, 4, 5) : __builtin_shufflevector(a, a, 6, 7);
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+a"(acc) : "v"(bh), "v"(ah));
   } else {
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc) : "v"(b), "v"(a), "v"(unit));
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[%5,%6,0] op_sel_hi:[%7,%8,0]"
+                 : "+a"(acc)
+                 : "v"(b), "v"(a), "v"(sb), "v"(sa), "n"(NBQ & 1), "n"(MBQ & 1), "n"(NBQ >> 1), "n"(MBQ >> 1));
+  }
+}
+template <int DT>
+__device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x8& b, int sub, int mbq, int nbq, int sa, int sb) {
+  if constexpr (DT != GMD_DT_MXFP8) {
+    mfma_step_t<DT, 0, 0>(acc, a, b, sub, 0, 0);
+  } else {
+    switch (mbq * 4 + nbq) {  // constant once the caller's loop is unrolled
+#define GMD_W4_CASE(MBQ, NBQ) \
+  case MBQ * 4 + NBQ: mfma_step_t<DT, MBQ, NBQ>(acc, a, b, 0, sa, sb); break;
+      GMD_W4_CASE(0, 0) GMD_W4_CASE(0, 1) GMD_W4_CASE(0, 2) GMD_W4_CASE(0, 3)
+      GMD_W4_CASE(1, 0) GMD_W4_CASE(1, 1) GMD_W4_CASE(1, 2) GMD_W4_CASE(1, 3)
+      GMD_W4_CASE(2, 0) GMD_W4_CASE(2, 1) GMD_W4_CASE(2, 2) GMD_W4_CASE(2, 3)
+      GMD_W4_CASE(3, 0) GMD_W4_CASE(3, 1) GMD_W4_CASE(3, 2) GMD_W4_CASE(3, 3)
+#undef GMD_W4_CASE
+    }
   }
 }
 #define W4_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 template <int DT, int ABL = 0, int EPI = 1>  // ABL 16: clock stamps (ablation builds only); EPI: see store_acc
 __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restrict__ A, const char* __restrict__ B,
-                                                             __bf16* __restrict__ C, int M, int N, size_t row_bytes) {
+                                                             __bf16* __restrict__ C, int M, int N, size_t row_bytes,
+                                                             const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB) {
+  constexpr bool kMx = DT == GMD_DT_MXFP8;
+  constexpr int kPerHalf = kMx ? 5 : 4;  // vector-memory instructions a wave issues per half-tile (MX: + its scale unit)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -839,13 +915,29 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
                                      (__attribute__((address_space(3))) void*)(my_pieces + slot * kHalfBytes + i * 1024), 16, 0, 0);
   };
+  // MX scales: the packed unit (256 B: 64 rows x 4 blocks of one K-tile) that belongs to a half-tile travels with
+  // it, by one 4-byte-per-lane LDS-DMA into this wave's own slot of a small ring behind the operand ring.
+  const int ktiles = (int)(row_bytes / BKB);
+  char* const my_scales = smem + kLdsBytes + wave * 8 * 256;
+  const uint32_t* sc_a = nullptr;
+  const uint32_t* sc_b = nullptr;
+  if constexpr (kMx) {
+    sc_a = SA + (size_t)(4 * tm + 2 * wr) * ktiles * kScaleUnitDwords + lane;
+    sc_b = SB + (size_t)(4 * tn + 2 * wc) * ktiles * kScaleUnitDwords + lane;
+  }
+  auto dma_scale = [&](int kind, int kt, int slot) {
+    const uint32_t* src = ((kind == 0 || kind == 3) ? sc_a : sc_b) + ((size_t)(kind >= 2 ? ktiles : 0) + kt) * kScaleUnitDwords;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(my_scales + slot * 256), 4, 0, 0);
+  };
+  auto read_scale = [&](int slot) { return *(const int*)(my_scales + slot * 256 + lane * 4); };
 
   // Fragment read offsets inside a slot (local rows: A wr*64 + fr, B wc*64 + fr).
   const int fr = lane & 15, fq = lane >> 4;
   int a_off[2], b_off[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
-    const int ch = DT == GMD_DT_BF16 ? ks * 4 + fq : 2 * fq + ks;
+    const int ch = ks * 4 + fq;
     a_off[ks] = lds_off<DT>(wr * 64 + fr, ch);
     b_off[ks] = lds_off<DT>(wc * 64 + fr, ch);
   }
@@ -862,8 +954,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   i32x8 aL[4], aH[4], bX[4], bY[4];
-  int unit;
-  asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(unit));
+  int sAL = 0, sAH = 0, sBX = 0, sBY = 0;  // MX: the scale dword that goes with each fragment set
 
   // Prologue: half-tiles 0..7 (K-tiles 0 and 1) in flight, 0..3 landed (phases 0 and 1 read 2 and 3), 0 and 1 in registers.
 #pragma unroll
@@ -871,13 +962,18 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     const char* base = piece_base(j & 3, j >> 2);
 #pragma unroll
     for (int i = 0; i < 4; i++) dma(base, j, i);
+    if constexpr (kMx) dma_scale(j & 3, j >> 2, j);
   }
-  wait_vmcnt<4 * (kAheadW4 - 4)>();
+  wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
   GMD_PHASE_FENCE();
 #pragma unroll
   for (int j = 0; j < 8; j++) read_one(aL, 0, true, j);
 #pragma unroll
   for (int j = 0; j < 8; j++) read_one(bX, 1, false, j);
+  if constexpr (kMx) {
+    sAL = read_scale(0);
+    sBX = read_scale(1);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   GMD_PHASE_FENCE();
 
@@ -898,16 +994,23 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     i32x8(&Rf)[4] = rk == 0 ? aL : rk == 3 ? aH : (rk == 1) == (rpar == 0) ? bX : bY;
     constexpr int rslot = R & 7;
     // issued during this phase: half-tile P+8, into the slot half-tile P leaves
-    const char* base = piece_base(p, min(kt0 + 2 + par, last_kt));
-    constexpr int NM = DT == GMD_DT_BF16 ? 32 : 16;
+    const int ikt = min(kt0 + 2 + par, last_kt);
+    const char* base = piece_base(p, ikt);
+    int& sAf = (p < 2) ? sAL : sAH;
+    int& sBf = (p == 0 || p == 3) ? (par ? sBY : sBX) : (par ? sBX : sBY);
+    int& sRf = rk == 0 ? sAL : rk == 3 ? sAH : (rk == 1) == (rpar == 0) ? sBX : sBY;
+    constexpr int NM = DT == GMD_DT_BF16 ? 32 : DT == GMD_DT_FP8 ? 64 : 16;
 #pragma unroll
     for (int i = 0; i < NM; i++) {
-      const int ks = DT == GMD_DT_BF16 ? i >> 4 : 0, mb = (i >> 2) & 3, nb = i & 3;
-      mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], ks, unit);
+      const int sub = i >> 4, mb = (i >> 2) & 3, nb = i & 3;
+      mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], sub, mb, nb, sAf, sBf);
       if (i < 8) read_one(Rf, rslot, rk == 0 || rk == 3, i);
       else if (i < 12) dma(base, P, i - 8);
-      if (i < 12) __builtin_amdgcn_sched_barrier(0);
+      else if (kMx && i == 12) dma_scale(p, ikt, P);
+      else if (kMx && i == 13) sRf = read_scale(rslot);
+      if (i < (kMx ? 14 : 12)) __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (kMx) asm volatile("" ::"v"(sAf), "v"(sBf));
     // Keep both operand sets whole until the phase's last MFMA, so that no half of them is handed to one of
     // this phase's ds_reads or address computations while MFMAs that read it are still to issue.
 #pragma unroll
@@ -916,7 +1019,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     // phases: after odd phase h, half-tiles up to h+4 have landed (h+1 and h+2 read h+3 and h+4) and the reads
     // of phases h-1 and h are done, which frees the slots that phases h+1 and h+2 refill.
     if constexpr (P & 1) {
-      wait_vmcnt<4 * (kAheadW4 - 4)>();
+      wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       GMD_PHASE_FENCE();
     } else {
@@ -987,6 +1090,64 @@ __global__ void fill_fp8_kernel(uint8_t* p, uint64_t n, uint64_t seed) {
     uint32_t h = hash32(i + seed);
     uint8_t mag = (uint8_t)(0x20 + (h & 0x1f));  // exponent 4..7, mantissa random: |x| in [2^-3, 2)
     p[i] = (uint8_t)(mag | ((h >> 8) & 1 ? 0x80 : 0));
+  }
+}
+
+// E8M0 block scales within 2^-3 .. 2^3 (row-major [rows][K/32]).
+__global__ void fill_e8m0_kernel(uint8_t* p, uint64_t n, uint64_t seed) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (uint8_t)(124 + hash32(i + seed) % 7);
+}
+
+// Row-major E8M0 scales [rows][kblocks] -> packed units (see the head of this file): one thread per packed dword.
+__global__ void pack_scales_kernel(const uint8_t* __restrict__ nat, uint32_t* __restrict__ packed, int rows, int kblocks) {
+  const int ktiles = kblocks / 4;
+  const uint64_t n = (uint64_t)(rows / 64) * ktiles * kScaleUnitDwords;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int d = (int)(i % kScaleUnitDwords), fq = d >> 4, fr = d & 15;
+    const uint64_t unit = i / kScaleUnitDwords;
+    const int kt = (int)(unit % ktiles), rg = (int)(unit / ktiles);
+    uint32_t v = 0;
+    for (int mb = 0; mb < 4; mb++) v |= (uint32_t)nat[(size_t)(64 * rg + 16 * mb + fr) * kblocks + 4 * kt + fq] << (8 * mb);
+    packed[i] = v;
+  }
+}
+
+// ---- independent reference for sampled C entries ---------------------------------
+// One wave per sample: the full-K dot product of row i of A and row j of B, decoded element by element and summed
+// in double.  Shares nothing with the GEMM kernels (no MFMA, no LDS, no tiling, row-major scales).
+__device__ __forceinline__ float e4m3_to_float(uint8_t v) {
+  const int e = (v >> 3) & 15, m = v & 7;
+  const float mag = e ? ldexpf(1.0f + m * 0.125f, e - 7) : ldexpf((float)m, -9);
+  return (v & 0x80) ? -mag : mag;
+}
+__global__ __launch_bounds__(64) void gemm_reference_kernel(int dtype, const void* __restrict__ A, const void* __restrict__ B,
+                                                            const uint8_t* __restrict__ sa, const uint8_t* __restrict__ sb,
+                                                            const __bf16* __restrict__ C, int M, int N, int K, uint64_t seed,
+                                                            float* __restrict__ ref, float* __restrict__ got) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int i = (int)(hash32(2ull * s + seed) % (uint32_t)M), j = (int)(hash32(2ull * s + 1 + seed) % (uint32_t)N);
+  double sum = 0;
+  for (int k = lane; k < K; k += 64) {
+    float x, y;
+    if (dtype == GMD_DT_BF16) {
+      x = (float)((const __bf16*)A)[(size_t)i * K + k];
+      y = (float)((const __bf16*)B)[(size_t)j * K + k];
+    } else {
+      x = e4m3_to_float(((const uint8_t*)A)[(size_t)i * K + k]);
+      y = e4m3_to_float(((const uint8_t*)B)[(size_t)j * K + k]);
+      if (dtype == GMD_DT_MXFP8) {
+        x *= ldexpf(1.0f, (int)sa[(size_t)i * (K / 32) + k / 32] - 127);
+        y *= ldexpf(1.0f, (int)sb[(size_t)j * (K / 32) + k / 32] - 127);
+      }
+    }
+    sum += (double)x * (double)y;
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (lane == 0) {
+    ref[s] = (float)sum;
+    got[s] = (float)C[(size_t)i * N + j];
   }
 }
 
@@ -1124,74 +1285,92 @@ int persistent_grid() {
   return grid;
 }
 
-// Launch one instantiation with 128 KiB of dynamic LDS.  The opt-in attribute is per function and device; it is
-// set again whenever the (kernel, device) pair differs from the calling thread's previous launch.
-typedef void (*gemm_fn_t)(const char*, const char*, __bf16*, int, int, size_t);
-int launch_lds128(gemm_fn_t kfn, int grid, int threads, hipStream_t st, const void* a, const void* b, void* c, int m, int n,
-                  size_t row_bytes) {
+// Launch one instantiation with its dynamic LDS (128 KiB operand ring; MX-fp8 adds 8 KiB of scale ring).  The
+// opt-in attribute is per function and device; it is set again whenever the (kernel, device) pair differs from the
+// calling thread's previous launch.
+typedef void (*gemm_fn_t)(const char*, const char*, __bf16*, int, int, size_t, const uint32_t*, const uint32_t*);
+struct GemmArgs {
+  const void *a, *b;
+  void* c;
+  int m, n;
+  size_t row_bytes;
+  const uint32_t *sa, *sb;  // packed MX scales (MX-fp8 only)
+  hipStream_t st;
+};
+int launch_lds(gemm_fn_t kfn, int grid, int threads, int lds_bytes, const GemmArgs& g) {
   thread_local gemm_fn_t last_fn = nullptr;
   thread_local int last_dev = -1;
   int dev = 0;
   GMD_HIP(hipGetDevice(&dev));
   if (last_fn != kfn || last_dev != dev) {
-    GMD_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    GMD_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     last_fn = kfn;
     last_dev = dev;
   }
-  kfn<<<grid, threads, kLdsBytes, st>>>((const char*)a, (const char*)b, (__bf16*)c, m, n, row_bytes);
+  kfn<<<grid, threads, lds_bytes, g.st>>>((const char*)g.a, (const char*)g.b, (__bf16*)g.c, g.m, g.n, g.row_bytes, g.sa, g.sb);
   GMD_HIP(hipGetLastError());
   return GMD_OK;
 }
 
+constexpr int kScaleRingBytes = 4 * 8 * 256;  // gemm_w4_kernel, MX-fp8: four waves x eight slots x one unit
+
 template <int DT>
-int launch_gemm_t(const void* a, const void* b, void* c, int m, int n, size_t row_bytes, hipStream_t st) {
-  const int grid = (m / BM) * (n / BN);
-  const size_t ktiles = row_bytes / BKB;
+int launch_gemm_t(const GemmArgs& g) {
+  constexpr bool kMx = DT == GMD_DT_MXFP8;
+  const int grid = (g.m / BM) * (g.n / BN);
+  const size_t ktiles = g.row_bytes / BKB;
   const bool pairs = ktiles >= 2 && (ktiles & 1) == 0;                      // the pipelines walk K-tiles in pairs
   const bool stream_ok = pairs && ktiles >= 4 && grid > persistent_grid();  // more tiles than CUs, two pairs per tile
-#define GMD_LAUNCH(KFN, GRID, THREADS) return launch_lds128(KFN, GRID, THREADS, st, a, b, c, m, n, row_bytes)
+#define GMD_LAUNCH(KFN, GRID, THREADS) return launch_lds(KFN, GRID, THREADS, kLdsBytes, g)
 #ifdef GMD_GEMM_ABLATE
   // Timing-only builds of the per-tile pipeline with parts removed (10 + mask), other issue distances (20 + d),
-  // clock stamps (41..46, 51) and the per-tile timeline of the streaming kernel (53).
-  switch (gemm_variant()) {
-    case 25: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 5>), grid, kThreads);
-    case 26: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 6>), grid, kThreads);
-    case 27: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 7>), grid, kThreads);
-    case 11: GMD_LAUNCH((gemm_pp_kernel<DT, 1>), grid, kThreads);
-    case 12: GMD_LAUNCH((gemm_pp_kernel<DT, 2>), grid, kThreads);
-    case 13: GMD_LAUNCH((gemm_pp_kernel<DT, 3>), grid, kThreads);
-    case 14: GMD_LAUNCH((gemm_pp_kernel<DT, 4>), grid, kThreads);
-    case 15: GMD_LAUNCH((gemm_pp_kernel<DT, 5>), grid, kThreads);
-    case 16: GMD_LAUNCH((gemm_pp_kernel<DT, 6>), grid, kThreads);
-    case 17: GMD_LAUNCH((gemm_pp_kernel<DT, 7>), grid, kThreads);
-    case 18: GMD_LAUNCH((gemm_pp_kernel<DT, 8>), grid, kThreads);    // full pipeline, operands always L2-resident
-    case 23: GMD_LAUNCH((gemm_pp_kernel<DT, 13>), grid, kThreads);   // DMA only, operands always L2-resident
-    case 33: GMD_LAUNCH((gemm_pp_kernel<DT, 5, 5>), grid, kThreads);  // DMA only at issue distance 5
-    case 34: GMD_LAUNCH((gemm_pp_kernel<DT, 5, 6>), grid, kThreads);  // DMA only at issue distance 6
-    case 41: GMD_LAUNCH((gemm_pp_kernel<DT, 16>), grid, kThreads);
-    case 42: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 3>), grid, kThreads);
-    case 43: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 1>), grid, kThreads);
-    case 44: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 2>), grid, kThreads);
-    case 45: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 5>), grid, kThreads);
-    case 46: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 8>), grid, kThreads);
-    case 51: GMD_LAUNCH((gemm_w4_kernel<DT, 16>), grid, kThreadsW4);
-    case 53: GMD_LAUNCH((gemm_ps_kernel<DT, 1, 16>), persistent_grid(), kThreads);
-    default: break;
+  // clock stamps (41..46, 51) and the per-tile timeline of the streaming kernel (53).  bf16 and fp8.
+  if constexpr (!kMx) {
+    switch (gemm_variant()) {
+      case 25: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 5>), grid, kThreads);
+      case 26: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 6>), grid, kThreads);
+      case 27: GMD_LAUNCH((gemm_pp_kernel<DT, 0, 7>), grid, kThreads);
+      case 11: GMD_LAUNCH((gemm_pp_kernel<DT, 1>), grid, kThreads);
+      case 12: GMD_LAUNCH((gemm_pp_kernel<DT, 2>), grid, kThreads);
+      case 13: GMD_LAUNCH((gemm_pp_kernel<DT, 3>), grid, kThreads);
+      case 14: GMD_LAUNCH((gemm_pp_kernel<DT, 4>), grid, kThreads);
+      case 15: GMD_LAUNCH((gemm_pp_kernel<DT, 5>), grid, kThreads);
+      case 16: GMD_LAUNCH((gemm_pp_kernel<DT, 6>), grid, kThreads);
+      case 17: GMD_LAUNCH((gemm_pp_kernel<DT, 7>), grid, kThreads);
+      case 18: GMD_LAUNCH((gemm_pp_kernel<DT, 8>), grid, kThreads);     // full pipeline, operands always L2-resident
+      case 23: GMD_LAUNCH((gemm_pp_kernel<DT, 13>), grid, kThreads);    // DMA only, operands always L2-resident
+      case 33: GMD_LAUNCH((gemm_pp_kernel<DT, 5, 5>), grid, kThreads);  // DMA only at issue distance 5
+      case 34: GMD_LAUNCH((gemm_pp_kernel<DT, 5, 6>), grid, kThreads);  // DMA only at issue distance 6
+      case 41: GMD_LAUNCH((gemm_pp_kernel<DT, 16>), grid, kThreads);
+      case 42: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 3>), grid, kThreads);
+      case 43: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 1>), grid, kThreads);
+      case 44: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 2>), grid, kThreads);
+      case 45: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 5>), grid, kThreads);
+      case 46: GMD_LAUNCH((gemm_pp_kernel<DT, 16 | 8>), grid, kThreads);
+      case 53: GMD_LAUNCH((gemm_ps_kernel<DT, 1, 16>), persistent_grid(), kThreads);
+      default: break;
+    }
   }
+  if (gemm_variant() == 51) return launch_lds(gemm_w4_kernel<DT, 16>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
 #endif
-  // auto: bf16 runs the eight-wave kernels (the stream when there are more tiles than CUs), MX-fp8 the four-wave one
+  // auto: bf16 and fp8 run the eight-wave kernels (the stream when there are more tiles than CUs), MX-fp8 the
+  // four-wave one, which is also the only pipeline that carries scales.
   int variant = gemm_variant();
-  if (variant < 0 || variant > kVariantMax) variant = DT == GMD_DT_BF16 ? 3 : 2;
+  if (variant < 0 || variant > kVariantMax) variant = kMx ? 2 : 3;
+  if (kMx && variant != 0) variant = 2;
   if (!pairs) variant = 0;
   if (variant == 3 && !stream_ok) variant = 1;
-  switch (variant) {
-    case 1: GMD_LAUNCH((gemm_pp_kernel<DT>), grid, kThreads);
-    case 2: GMD_LAUNCH((gemm_w4_kernel<DT>), grid, kThreadsW4);
-    case 3: GMD_LAUNCH((gemm_ps_kernel<DT>), persistent_grid(), kThreads);
-    case 4: GMD_LAUNCH((gemm_pp_kernel<DT, 0, kAheadDefault, 0>), grid, kThreads);
-    case 5: GMD_LAUNCH((gemm_pp_kernel<DT, 0, kAheadDefault, 2>), grid, kThreads);
-    default: GMD_LAUNCH((gemm_kernel<DT>), grid, kThreads);
+  if (variant == 2) return launch_lds(gemm_w4_kernel<DT>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
+  if constexpr (!kMx) {
+    switch (variant) {
+      case 1: GMD_LAUNCH((gemm_pp_kernel<DT>), grid, kThreads);
+      case 3: GMD_LAUNCH((gemm_ps_kernel<DT>), persistent_grid(), kThreads);
+      case 4: GMD_LAUNCH((gemm_pp_kernel<DT, 0, kAheadDefault, 0>), grid, kThreads);
+      case 5: GMD_LAUNCH((gemm_pp_kernel<DT, 0, kAheadDefault, 2>), grid, kThreads);
+      default: break;
+    }
   }
+  GMD_LAUNCH((gemm_kernel<DT>), grid, kThreads);
 #undef GMD_LAUNCH
 }
 
@@ -1238,36 +1417,64 @@ int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles) {
 #endif
 }
 
-int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream) {
+static int gemm_launch_checked(int dtype, const void* a, const void* b, const void* sa, const void* sb, void* c, int m, int n, int k,
+                               void* hip_stream) {
   if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || (m % BM) || (n % BN)) return GMD_ERR_BADPARAM;
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return GMD_ERR_BADPARAM;
-  hipStream_t st = (hipStream_t)hip_stream;
-  if (dtype == GMD_DT_BF16) {
-    if (k % 64) return GMD_ERR_BADPARAM;
-    return launch_gemm_t<GMD_DT_BF16>(a, b, c, m, n, (size_t)k * 2, st);
+  GemmArgs g{a, b, c, m, n, 0, (const uint32_t*)sa, (const uint32_t*)sb, (hipStream_t)hip_stream};
+  switch (dtype) {
+    case GMD_DT_BF16:
+      if (k % 64) return GMD_ERR_BADPARAM;
+      g.row_bytes = (size_t)k * 2;
+      return launch_gemm_t<GMD_DT_BF16>(g);
+    case GMD_DT_FP8:
+      if (k % 128) return GMD_ERR_BADPARAM;
+      g.row_bytes = (size_t)k;
+      return launch_gemm_t<GMD_DT_FP8>(g);
+    case GMD_DT_MXFP8:
+      if ((k % 128) || !sa || !sb || (((uintptr_t)sa | (uintptr_t)sb) & 3)) {
+        gmd::set_error("MX-fp8 GEMM: K must be a multiple of 128 and both packed scale tensors are required (gmd_gemm_launch_mx)");
+        return GMD_ERR_BADPARAM;
+      }
+      g.row_bytes = (size_t)k;
+      return launch_gemm_t<GMD_DT_MXFP8>(g);
+    default: return GMD_ERR_BADPARAM;
   }
-  if (dtype == GMD_DT_FP8 || dtype == GMD_DT_MXFP8) {
-    if (k % 128) return GMD_ERR_BADPARAM;
-    return launch_gemm_t<GMD_DT_MXFP8>(a, b, c, m, n, (size_t)k, st);
-  }
-  return GMD_ERR_BADPARAM;
+}
+
+int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream) {
+  return gemm_launch_checked(dtype, a, b, nullptr, nullptr, c, m, n, k, hip_stream);
+}
+
+int gmd_gemm_launch_mx(const void* a, const void* b, const void* scale_a_packed, const void* scale_b_packed, void* c, int m, int n,
+                       int k, void* hip_stream) {
+  return gemm_launch_checked(GMD_DT_MXFP8, a, b, scale_a_packed, scale_b_packed, c, m, n, k, hip_stream);
+}
+
+int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int rows, int k, void* hip_stream) {
+  if (!scales_row_major || !packed || rows <= 0 || k <= 0 || (rows % 64) || (k % 128) || ((uintptr_t)packed & 3)) return GMD_ERR_BADPARAM;
+  pack_scales_kernel<<<1024, 256, 0, (hipStream_t)hip_stream>>>((const uint8_t*)scales_row_major, (uint32_t*)packed, rows, k / 32);
+  GMD_HIP(hipGetLastError());
+  return GMD_OK;
 }
 
 int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, int verify, gmd_mfma_result_t* out) {
   if (!out) return GMD_ERR_BADPARAM;
   memset(out, 0, sizeof *out);
   const bool fp8 = dtype == GMD_DT_FP8 || dtype == GMD_DT_MXFP8;
+  const bool mx = dtype == GMD_DT_MXFP8;
   if (dtype != GMD_DT_BF16 && !fp8) return GMD_ERR_BADPARAM;
   if (m <= 0 || n <= 0 || k <= 0 || (m % BM) || (n % BN) || (k % (fp8 ? 128 : 64))) return GMD_ERR_BADPARAM;
   GMD_HIP(hipSetDevice(device));
   const size_t esz = fp8 ? 1 : 2;
-  gmd::DeviceBuffer a, b, c, sums;
+  gmd::DeviceBuffer a, b, c, sums, sa_nat, sb_nat, sa_pk, sb_pk, refs;
   int rc;
   // Checksums land in a window of slots that is drained to the host (compared, cleared) whenever it is
   // full, so the soak runs for as long as it is asked to.
   const int kWindow = 1 << 13;
+  const int kSamples = 4096;
   if ((rc = a.alloc((size_t)m * k * esz)) || (rc = b.alloc((size_t)n * k * esz)) || (rc = c.alloc((size_t)m * n * 2)) ||
-      (rc = sums.alloc(sizeof(unsigned long long) * kWindow)))
+      (rc = sums.alloc(sizeof(unsigned long long) * kWindow)) || (rc = refs.alloc(sizeof(float) * 2 * kSamples)))
     return rc;
   if (fp8) {
     fill_fp8_kernel<<<2048, 256>>>((uint8_t*)a.p, (uint64_t)m * k, 1);
@@ -1276,10 +1483,45 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
     fill_bf16_kernel<<<2048, 256>>>((__bf16*)a.p, (uint64_t)m * k, 1);
     fill_bf16_kernel<<<2048, 256>>>((__bf16*)b.p, (uint64_t)n * k, 2);
   }
+  if (mx) {  // one E8M0 scale per row and 32 k, row-major for the reference and packed for the kernel
+    if ((rc = sa_nat.alloc((size_t)m * (k / 32))) || (rc = sb_nat.alloc((size_t)n * (k / 32))) || (rc = sa_pk.alloc((size_t)m * (k / 32))) ||
+        (rc = sb_pk.alloc((size_t)n * (k / 32))))
+      return rc;
+    fill_e8m0_kernel<<<256, 256>>>((uint8_t*)sa_nat.p, (uint64_t)m * (k / 32), 3);
+    fill_e8m0_kernel<<<256, 256>>>((uint8_t*)sb_nat.p, (uint64_t)n * (k / 32), 4);
+    if ((rc = gmd_mx_pack_scales(sa_nat.p, sa_pk.p, m, k, nullptr)) || (rc = gmd_mx_pack_scales(sb_nat.p, sb_pk.p, n, k, nullptr))) return rc;
+  }
+  auto launch = [&]() { return gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, c.p, m, n, k, nullptr); };
   GMD_HIP(hipMemset(sums.p, 0, sizeof(unsigned long long) * kWindow));
   GMD_HIP(hipGetLastError());
-  if ((rc = gmd_gemm_launch(dtype, a.p, b.p, c.p, m, n, k, nullptr))) return rc;  // warm-up
+  if ((rc = launch())) return rc;  // warm-up; also the launch that is checked against the reference
   GMD_HIP(hipDeviceSynchronize());
+  if (verify) {
+    // kSamples entries of C against full-K dot products from a kernel that shares nothing with the GEMM.  bf16
+    // rounding of C is 2^-9 relative; the tolerance is twice that, measured against |ref| + rms(ref) so that
+    // entries near zero do not decide.
+    gemm_reference_kernel<<<kSamples, 64>>>(dtype, a.p, b.p, (const uint8_t*)sa_nat.p, (const uint8_t*)sb_nat.p, (const __bf16*)c.p, m, n, k,
+                                            0x5eed, (float*)refs.p, (float*)refs.p + kSamples);
+    GMD_HIP(hipGetLastError());
+    std::vector<float> h(2 * kSamples);
+    GMD_HIP(hipMemcpy(h.data(), refs.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    double sq = 0;
+    for (int i = 0; i < kSamples; i++) sq += (double)h[i] * h[i];
+    const double rms = std::sqrt(sq / kSamples);
+    double worst = 0;
+    bool finite = rms > 0 && std::isfinite(rms);
+    for (int i = 0; i < kSamples && finite; i++) {
+      if (!std::isfinite(h[kSamples + i])) finite = false;
+      worst = std::max(worst, std::fabs((double)h[kSamples + i] - h[i]) / (std::fabs((double)h[i]) + rms));
+    }
+    out->max_rel_err = finite ? worst : INFINITY;
+    if (!finite || worst > 4e-3) {
+      out->verified = -1;
+      gmd::set_error("GEMM stress: the first launch differs from the fp32 reference (max relative error %.3g over %d sampled entries)",
+                     out->max_rel_err, kSamples);
+      return GMD_ERR_VERIFY;
+    }
+  }
 
   const uint64_t n16 = (uint64_t)m * n * 2 / 16;
   hipEvent_t e0, e1;
@@ -1306,7 +1548,7 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
     const int batch = 8;
     GMD_HIP(hipEventRecord(e0, 0));
     for (int i = 0; i < batch; i++) {
-      if ((rc = gmd_gemm_launch(dtype, a.p, b.p, c.p, m, n, k, nullptr))) return rc;
+      if ((rc = launch())) return rc;
       if (verify) checksum_kernel<<<1024, 256>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + in_window + i);
     }
     GMD_HIP(hipEventRecord(e1, 0));

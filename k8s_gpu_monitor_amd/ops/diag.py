@@ -85,6 +85,9 @@ def _lib():
                                       C.POINTER(MfmaResult)]
         L.gmd_gemm_launch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]
+        L.gmd_gemm_launch_mx.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p]
+        L.gmd_mx_pack_scales.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _typed = True
     return L
 
@@ -187,9 +190,9 @@ def gemm_stress(dtype="bf16", m=8192, n=8192, k=8192, seconds=2.0, verify=True, 
 
 
 def gemm_set_variant(variant):
-    """-1 = fastest pipeline per dtype (default), 1 = eight waves x 128x64, 2 = four waves x 128x128
-    (accumulators in AGPRs), 3 = eight waves x 128x64 as a persistent grid (one workgroup per CU),
-    0 = simple double-buffered loop (A/B baseline)."""
+    """-1 = fastest schedule per dtype and shape (default), 0 = simple double-buffered loop (A/B baseline),
+    1 = eight waves x 128x64 per tile, 2 = four waves x 128x128 (accumulators in AGPRs), 3 = eight waves x 128x64
+    as one stream per CU over its tiles, 4 / 5 = schedule 1 with the narrow / cached epilogue."""
     rc = _lib().gmd_gemm_set_variant(int(variant))
     if rc:
         raise DiagError(rc, "gmd_gemm_set_variant")
@@ -256,8 +259,22 @@ def p2p_matrix(devices=None, bytes=256 << 20, iters=5):
     return [[m[i * n + j] for j in range(n)] for i in range(n)]
 
 
-def gemm_launch(dtype, a_ptr, b_ptr, c_ptr, m, n, k, stream=None):
-    """C[M,N] (bf16) = A[M,K] @ B[N,K]^T on caller memory."""
-    rc = _lib().gmd_gemm_launch(DTYPES[dtype], a_ptr, b_ptr, c_ptr, m, n, k, stream)
+def gemm_launch(dtype, a_ptr, b_ptr, c_ptr, m, n, k, stream=None, scale_a=None, scale_b=None):
+    """C[M,N] (bf16) = A[M,K] @ B[N,K]^T on caller memory.  dtype "mxfp8" takes the two packed E8M0 scale tensors
+    (mx_pack_scales) as scale_a / scale_b device pointers; "fp8" is unscaled e4m3."""
+    if dtype == "mxfp8":
+        if scale_a is None or scale_b is None:
+            raise DiagError(-1, "gmd_gemm_launch_mx: mxfp8 needs scale_a and scale_b (packed E8M0 scales)")
+        rc = _lib().gmd_gemm_launch_mx(C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_void_p(scale_a), C.c_void_p(scale_b),
+                                       C.c_void_p(c_ptr), m, n, k, C.c_void_p(stream))
+    else:
+        rc = _lib().gmd_gemm_launch(DTYPES[dtype], a_ptr, b_ptr, c_ptr, m, n, k, stream)
     if rc:
         raise DiagError(rc, f"gmd_gemm_launch({dtype})")
+
+
+def mx_pack_scales(src_ptr, dst_ptr, rows, k, stream=None):
+    """Row-major uint8 E8M0 scales [rows][k/32] -> the packed layout the MX-fp8 GEMM reads (same byte count)."""
+    rc = _lib().gmd_mx_pack_scales(C.c_void_p(src_ptr), C.c_void_p(dst_ptr), rows, k, C.c_void_p(stream))
+    if rc:
+        raise DiagError(rc, "gmd_mx_pack_scales")

@@ -21,27 +21,45 @@ SIZES = tuple(int(x) for x in os.environ.get("GEMM_AB_SIZES", "4096,8192,16384")
 PERSISTENT = tuple(int(x) for x in os.environ.get("GEMM_AB_PERSISTENT", "3").split(","))
 
 
-def inputs(m, n, k, dtype, seed=0):
-    g = torch.Generator(device=dev).manual_seed(seed)
-    a = torch.randn(m, k, device=dev, generator=g)
-    b = torch.randn(n, k, device=dev, generator=g)
-    if dtype == "bf16":
-        return a.bfloat16(), b.bfloat16()
-    return a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+class Case:
+    """Operands of one GEMM; MX-fp8 carries random E8M0 scales (2^-3 .. 2^3), row-major for the reference and packed."""
+
+    def __init__(self, m, n, k, dtype, seed=0):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        a = torch.randn(m, k, device=dev, generator=g)
+        b = torch.randn(n, k, device=dev, generator=g)
+        self.m, self.n, self.k, self.dtype = m, n, k, dtype
+        self.a, self.b = (a.bfloat16(), b.bfloat16()) if dtype == "bf16" else (a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn))
+        self.kw, self.sa, self.sb = {}, None, None
+        if dtype == "mxfp8":
+            self.sa = torch.randint(124, 131, (m, k // 32), dtype=torch.uint8, device=dev, generator=g)
+            self.sb = torch.randint(124, 131, (n, k // 32), dtype=torch.uint8, device=dev, generator=g)
+            self.pa, self.pb = torch.empty_like(self.sa), torch.empty_like(self.sb)
+            diag.mx_pack_scales(self.sa.data_ptr(), self.pa.data_ptr(), m, k, stream)
+            diag.mx_pack_scales(self.sb.data_ptr(), self.pb.data_ptr(), n, k, stream)
+            self.kw = {"scale_a": self.pa.data_ptr(), "scale_b": self.pb.data_ptr()}
+
+    def ref(self):
+        dq = lambda x, s: x.float() if s is None else x.float() * torch.exp2(s.float() - 127).repeat_interleave(32, dim=1)
+        return dq(self.a, self.sa) @ dq(self.b, self.sb).t()
+
+    def launch(self, c):
+        diag.gemm_launch(self.dtype, self.a.data_ptr(), self.b.data_ptr(), c.data_ptr(), self.m, self.n, self.k, stream, **self.kw)
 
 
+DTYPES = tuple(os.environ.get("GEMM_AB_DTYPES", "bf16,fp8,mxfp8").split(","))
 ok_all = True
-for dtype in ("bf16", "mxfp8"):
-    for (m, n, k) in [(256, 256, 256), (512, 768, 1024), (1024, 256, 4096), (2048, 2048, 2048), (256, 512, 128 * 3 if dtype == "mxfp8" else 64 * 6),
+for dtype in DTYPES:
+    for (m, n, k) in [(256, 256, 256), (512, 768, 1024), (1024, 256, 4096), (2048, 2048, 2048), (256, 512, 64 * 6 if dtype == "bf16" else 128 * 3),
                       (4352, 4352, 512), (8192, 4096, 256), (2304, 8192, 1280)]:  # > 256 tiles: the persistent grid loops
-        a, b = inputs(m, n, k, dtype, seed=m + n + k)
-        ref = a.float() @ b.float().t()
+        case = Case(m, n, k, dtype, seed=m + n + k)
+        ref = case.ref()
         res = {}
         for v in VARIANTS:
             diag.gemm_set_variant(v)
             c = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=dev)
             for _ in range(3):  # repeated: a race would show as run-to-run differences
-                diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, stream)
+                case.launch(c)
             torch.cuda.synchronize()
             res[v] = c.clone()
             err = ((c.float() - ref).abs().max() / ref.abs().max()).item()
@@ -55,21 +73,21 @@ for dtype in ("bf16", "mxfp8"):
               flush=True)
 
 # race screen: many launches of the pipeline variant must give one bit pattern
-for rv, dtype in [(v, d) for v in VARIANTS if v != 0 for d in ("bf16", "mxfp8")]:
+for rv, dtype in [(v, d) for v in VARIANTS if v != 0 for d in DTYPES]:
     diag.gemm_set_variant(rv)
     S = 8192 if rv in PERSISTENT else 4096  # the persistent grid needs more tiles than CUs
-    a, b = inputs(S, S, 4096, dtype, seed=5)
+    case = Case(S, S, 4096, dtype, seed=5)
     c = torch.empty(S, S, dtype=torch.bfloat16, device=dev)
-    diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), S, S, 4096, stream)
+    case.launch(c)
     torch.cuda.synchronize()
     first = c.clone()
     bad = 0
     for i in range(200):
-        diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), S, S, 4096, stream)
+        case.launch(c)
         if i % 20 == 19:
             torch.cuda.synchronize()
             bad += int(not torch.equal(c, first))
-    ref = a.float() @ b.float().t()
+    ref = case.ref()
     err = ((first.float() - ref).abs().max() / ref.abs().max()).item()
     out["numerics"].append({"dtype": dtype, "variant": rv, "race_screen_mismatches": bad, "rel_err_4096": err})
     ok_all &= bad == 0 and err < 6e-3
@@ -88,9 +106,9 @@ def timeit(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-for dtype in ("bf16", "mxfp8"):
+for dtype in DTYPES:
     for s in SIZES:
-        a, b = inputs(s, s, s, dtype, seed=s)
+        case = Case(s, s, s, dtype, seed=s)
         c = torch.empty(s, s, dtype=torch.bfloat16, device=dev)
         flops = 2.0 * s ** 3
         best = {v: 1e9 for v in VARIANTS + ("torch",)}
@@ -99,12 +117,12 @@ for dtype in ("bf16", "mxfp8"):
         for rep in range(int(os.environ.get("GEMM_AB_REPS", "4"))):  # interleaved A/B
             for v in VARIANTS:
                 diag.gemm_set_variant(v)
-                ms = timeit(lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), s, s, s, stream), n)
+                ms = timeit(lambda: case.launch(c), n)
                 best[v] = min(best[v], ms)
                 allms[v].append(ms)
             if dtype == "bf16":
-                bt = b.t()
-                ms = timeit(lambda: torch.matmul(a, bt), n)
+                bt = case.b.t()
+                ms = timeit(lambda: torch.matmul(case.a, bt), n)
                 best["torch"] = min(best["torch"], ms)
                 allms["torch"].append(ms)
         row = {"dtype": dtype, "size": s}
@@ -115,7 +133,7 @@ for dtype in ("bf16", "mxfp8"):
             row["median_ms_torch"] = sorted(allms["torch"])[len(allms["torch"]) // 2]
         out["timing"].append(row)
         print(row, flush=True)
-        del a, b, c
+        del case, c
 diag.gemm_set_variant(-1)
 out["ok"] = ok_all
 os.makedirs("gpurun_out", exist_ok=True)

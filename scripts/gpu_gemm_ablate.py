@@ -24,7 +24,7 @@ if os.environ.get("GEMM_ABLATE_ONLY"):
     NAMES = {v: NAMES[v] for v in [1] + [int(x) for x in os.environ["GEMM_ABLATE_ONLY"].split(",")]}
 out = []
 # the issue-distance variants must compute the same bits as the simple loop, launch after launch
-for dtype in ("bf16", "mxfp8"):
+for dtype in ("bf16", "fp8"):
     for (m, n, k) in [(512, 768, 1024), (4096, 4096, 4096)]:
         a = torch.randn(m, k, device=dev)
         b = torch.randn(n, k, device=dev)
@@ -44,7 +44,7 @@ for dtype in ("bf16", "mxfp8"):
                     bad += int(not torch.equal(c, ref))
             print("numerics", dtype, (m, n, k), "variant", v, "mismatching checks", bad, flush=True)
             out.append({"dtype": dtype, "shape": [m, n, k], "variant": v, "mismatches": bad})
-for dtype in ("bf16", "mxfp8"):
+for dtype in ("bf16", "fp8"):
     s = 8192
     a = torch.randn(s, s, device=dev)
     b = torch.randn(s, s, device=dev)

@@ -28,7 +28,7 @@ ARMS = {41: "full", 42: "mfma + barriers", 43: "no reads", 44: "no dma", 45: "dm
 if os.environ.get("GEMM_CLOCK_ONLY"):
     ARMS = {int(v): ARMS[int(v)] for v in os.environ["GEMM_CLOCK_ONLY"].split(",")}
 out = []
-for dtype in ("bf16", "mxfp8"):
+for dtype in ("bf16", "fp8"):
     s = 8192
     a = torch.randn(s, s, device=dev)
     b = torch.randn(s, s, device=dev)

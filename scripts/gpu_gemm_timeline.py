@@ -27,7 +27,7 @@ out = []
 s = 8192
 ntiles = (s // 256) ** 2
 GRID = 256
-for dtype, variant in [(d, v) for d in os.environ.get("GEMM_TL_DTYPES", "bf16,mxfp8").split(",")
+for dtype, variant in [(d, v) for d in os.environ.get("GEMM_TL_DTYPES", "bf16,fp8").split(",")
                        for v in (int(x) for x in os.environ.get("GEMM_TL_VARIANTS", "53").split(","))]:
     a = torch.randn(s, s, device=dev)
     b = torch.randn(s, s, device=dev)

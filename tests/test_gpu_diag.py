@@ -149,37 +149,106 @@ def test_memtest_driver_with_injection(diag):
 
 
 # ------------------------------------------------------------------- MFMA GEMM --
-def _gemm_inputs(dev, m, n, k, dtype, seed):
-    g = torch.Generator(device=dev).manual_seed(seed)
-    a = torch.randn(m, k, device=dev, generator=g)
-    b = torch.randn(n, k, device=dev, generator=g)
-    if dtype == "bf16":
-        return a.bfloat16(), b.bfloat16()
-    return a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+class _Gemm:
+    """Operands of one GEMM case: A [m,k], B [n,k]; for MX-fp8 also row-major E8M0 scales [rows, k/32] and their
+    packed form.  ref() is the fp32 product of the dequantised operands."""
+
+    def __init__(self, diag, dev, m, n, k, dtype, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        a = torch.randn(m, k, device=dev, generator=g)
+        b = torch.randn(n, k, device=dev, generator=g)
+        self.diag, self.dtype, self.m, self.n, self.k = diag, dtype, m, n, k
+        self.sa = self.sb = self.pa = self.pb = None
+        if dtype == "bf16":
+            self.a, self.b = a.bfloat16(), b.bfloat16()
+        else:
+            self.a, self.b = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+        if dtype == "mxfp8":
+            self.sa = torch.randint(122, 133, (m, k // 32), dtype=torch.uint8, device=dev, generator=g)  # 2^-5 .. 2^5
+            self.sb = torch.randint(122, 133, (n, k // 32), dtype=torch.uint8, device=dev, generator=g)
+            self.pa, self.pb = torch.empty_like(self.sa), torch.empty_like(self.sb)
+            diag.mx_pack_scales(self.sa.data_ptr(), self.pa.data_ptr(), m, k, _stream())
+            diag.mx_pack_scales(self.sb.data_ptr(), self.pb.data_ptr(), n, k, _stream())
+
+    @staticmethod
+    def _dq(x, s):
+        x = x.float()
+        return x if s is None else x * torch.exp2(s.float() - 127.0).repeat_interleave(32, dim=1)
+
+    def ref(self):
+        return self._dq(self.a, self.sa) @ self._dq(self.b, self.sb).t()
+
+    def launch(self, c, a=None, pa=None):
+        a = self.a if a is None else a
+        pa = self.pa if pa is None else pa
+        kw = {} if self.dtype != "mxfp8" else {"scale_a": pa.data_ptr(), "scale_b": self.pb.data_ptr()}
+        self.diag.gemm_launch(self.dtype, a.data_ptr(), self.b.data_ptr(), c.data_ptr(), self.m, self.n, self.k, _stream(), **kw)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8", "mxfp8"])
 @pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1024), (1024, 256, 4096), (2048, 2048, 2048)])
 def test_gemm_matches_fp32_reference(diag, dev, dtype, shape):
     m, n, k = shape
-    a, b = _gemm_inputs(dev, m, n, k, dtype, seed=m + n + k)
+    G = _Gemm(diag, dev, m, n, k, dtype, seed=m + n + k)
     c = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=dev)
-    diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, _stream())
+    G.launch(c)
     torch.cuda.synchronize()
-    ref = a.float() @ b.float().t()
+    ref = G.ref()
     assert torch.isfinite(c.float()).all()
     err = (c.float() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 6e-3, err  # bf16 output rounding: 2^-8 relative
-    # every tile position is its own product: permuting rows of A permutes rows of C
+    # every tile position is its own product: permuting rows of A (and of its scales) permutes rows of C
     perm = torch.randperm(m, device=dev)
     c2 = torch.empty_like(c)
-    ap = a.view(torch.uint8 if dtype != "bf16" else torch.bfloat16)[perm].contiguous()
-    diag.gemm_launch(dtype, ap.data_ptr(), b.data_ptr(), c2.data_ptr(), m, n, k, _stream())
+    ap = G.a.view(torch.uint8 if dtype != "bf16" else torch.bfloat16)[perm].contiguous()
+    pa = None
+    if dtype == "mxfp8":
+        pa = torch.empty_like(G.pa)
+        sp = G.sa[perm].contiguous()
+        diag.mx_pack_scales(sp.data_ptr(), pa.data_ptr(), m, k, _stream())
+    G.launch(c2, a=ap, pa=pa)
     torch.cuda.synchronize()
     assert torch.equal(c2, c[perm])
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "mxfp8"])
+def test_mx_scales_are_applied_per_row_and_per_block_of_32(diag, dev):
+    """Operands of all ones: C[i][j] is then the sum over the K/32 blocks of 32 * 2^(sa[i][blk] + sb[j][blk] - 254),
+    so a scale read from the wrong row, the wrong block or the wrong byte of a packed dword changes the answer.
+    Unit scales must reproduce the unscaled fp8 kernel bit for bit."""
+    m, n, k = 512, 256, 1024
+    one = torch.ones(max(m, n), k, device=dev).to(torch.float8_e4m3fn)
+    g = torch.Generator(device=dev).manual_seed(3)
+    sa = torch.randint(124, 131, (m, k // 32), dtype=torch.uint8, device=dev, generator=g)
+    sb = torch.randint(124, 131, (n, k // 32), dtype=torch.uint8, device=dev, generator=g)
+    pa, pb = torch.empty_like(sa), torch.empty_like(sb)
+    diag.mx_pack_scales(sa.data_ptr(), pa.data_ptr(), m, k, _stream())
+    diag.mx_pack_scales(sb.data_ptr(), pb.data_ptr(), n, k, _stream())
+    c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+    try:
+        for variant in (0, 2):
+            diag.gemm_set_variant(variant)
+            diag.gemm_launch("mxfp8", one.data_ptr(), one.data_ptr(), c.data_ptr(), m, n, k, _stream(), scale_a=pa.data_ptr(),
+                             scale_b=pb.data_ptr())
+            torch.cuda.synchronize()
+            ref = 32.0 * (torch.exp2(sa.double() - 127) @ torch.exp2(sb.double() - 127).t())
+            assert torch.equal(c, ref.float().bfloat16()), variant  # sums of powers of two: exact in fp32
+    finally:
+        diag.gemm_set_variant(-1)
+    a8 = torch.randn(m, k, device=dev).to(torch.float8_e4m3fn)
+    b8 = torch.randn(n, k, device=dev).to(torch.float8_e4m3fn)
+    unit = torch.full((max(m, n), k // 32), 127, dtype=torch.uint8, device=dev)  # all-equal bytes: packing changes nothing
+    c_fp8 = torch.empty_like(c)
+    diag.gemm_launch("mxfp8", a8.data_ptr(), b8.data_ptr(), c.data_ptr(), m, n, k, _stream(), scale_a=unit.data_ptr(), scale_b=unit.data_ptr())
+    diag.gemm_launch("fp8", a8.data_ptr(), b8.data_ptr(), c_fp8.data_ptr(), m, n, k, _stream())
+    torch.cuda.synchronize()
+    ref = a8.float() @ b8.float().t()
+    for out in (c, c_fp8):
+        assert ((out.float() - ref).abs().max() / ref.abs().max()).item() < 6e-3
+    with pytest.raises(diag.DiagError):  # mxfp8 without scales is refused, it is not an fp8 GEMM under another name
+        diag.gemm_launch("mxfp8", a8.data_ptr(), b8.data_ptr(), c.data_ptr(), m, n, k, _stream())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8", "mxfp8"])
 def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
     """The pipelined schedules (eight waves x 128x64 per tile, the same as one stream per CU over its
     tiles, four waves x 128x128 with AGPR accumulators, the narrow and the cached epilogue) and the simple
@@ -187,23 +256,24 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
     launches of a pipeline must not differ either (a race between LDS-DMA and fragment reads, a store
     counted as a landed fetch, or a missed wait state around the hand-placed MFMAs, would show as
     run-to-run differences).  K-tile counts of 2 (prologue + one pair), 4, 32 and 128 exercise the loop
-    entry and the surplus issue of the last pair; an odd number of K-tiles takes the fallback path."""
-    kt = 128 if dtype == "mxfp8" else 64  # elements per 128-byte K-tile
+    entry and the surplus issue of the last pair; an odd number of K-tiles takes the fallback path.
+    MX-fp8 has two schedules (simple loop, four waves); the others fall back to the four-wave one."""
+    kt = 64 if dtype == "bf16" else 128  # elements per 128-byte K-tile
     try:
         for (m, n, k) in [(512, 512, 2 * kt), (256, 512, 4 * kt), (512, 512, 32 * kt), (1024, 768, 128 * kt), (256, 256, 3 * kt),
                           (4352, 4352, 4 * kt), (4352, 4608, 10 * kt)]:  # 289 / 306 tiles: more than CUs, variant 3 streams
-            a, b = _gemm_inputs(dev, m, n, k, dtype, seed=k)
+            G = _Gemm(diag, dev, m, n, k, dtype, seed=k)
             outs = {}
             for variant in (0, 1, 2, 3, 4, 5, -1):
                 diag.gemm_set_variant(variant)
                 c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
-                diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, _stream())
+                G.launch(c)
                 torch.cuda.synchronize()
                 outs[variant] = c
                 if variant in (1, 2, 3):  # 4 and 5 differ from 1 in the epilogue only
                     c2 = torch.empty_like(c)
                     for _ in range(20):
-                        diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c2.data_ptr(), m, n, k, _stream())
+                        G.launch(c2)
                     torch.cuda.synchronize()
                     assert torch.equal(c2, c), (variant, m, n, k)
             for variant in (1, 2, 3, 4, 5, -1):
@@ -220,7 +290,7 @@ def test_gemm_rejects_shapes_the_tiling_cannot_cover(diag, dev):
         with pytest.raises(diag.DiagError):
             diag.gemm_launch("bf16", x.data_ptr(), x.data_ptr(), x.data_ptr(), m, n, k, _stream())
     with pytest.raises(diag.DiagError):
-        diag.gemm_launch("mxfp8", x.data_ptr(), x.data_ptr(), x.data_ptr(), 512, 512, 192, _stream())
+        diag.gemm_launch("fp8", x.data_ptr(), x.data_ptr(), x.data_ptr(), 512, 512, 192, _stream())
 
 
 def test_gemm_stress_and_pipe_peak(diag):
