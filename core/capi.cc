@@ -2,10 +2,14 @@
 // wrapper per gpumon.h entry point.
 #include <csignal>
 #include <dlfcn.h>
+#include <cstring>
 #include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
+
+extern char** environ;
 
 #include "common/util.h"
 #include "engine/engine.h"
@@ -89,11 +93,10 @@ std::string find_hostengine(const char* hint) {
 }
 
 void stop_child(Global& g) {
-  if (g.child <= 0) return;
   // Polite stop with a 10 s grace, then SIGKILL — the same escalation as the
   // reference's exporter script (dcgm-exporter:198-217).
-  kill(g.child, SIGTERM);
-  for (int i = 0; i < 100; i++) {
+  if (g.child > 0) kill(g.child, SIGTERM);
+  for (int i = 0; i < 100 && g.child > 0; i++) {
     int status;
     if (waitpid(g.child, &status, WNOHANG) == g.child) {
       g.child = -1;
@@ -106,7 +109,11 @@ void stop_child(Global& g) {
     waitpid(g.child, nullptr, 0);
     g.child = -1;
   }
-  if (!g.child_socket.empty()) unlink(g.child_socket.c_str());
+  if (!g.child_socket.empty()) {
+    unlink(g.child_socket.c_str());
+    const size_t slash = g.child_socket.rfind('/');
+    if (slash != std::string::npos && slash > 0) rmdir(g.child_socket.substr(0, slash).c_str());  // its private directory
+  }
   g.child_socket.clear();
 }
 
@@ -147,27 +154,34 @@ gm_status_t do_init(Global& g, const gm_init_params_t* p) {
       GM_LOGE("gpumon-hostengine not found (set GPUMON_HOSTENGINE or PATH)");
       return GM_ST_CHILD_SPAWN_FAILED;
     }
-    char tmpl[] = "/tmp/gpumonXXXXXX";
-    int tfd = mkstemp(tmpl);
-    if (tfd < 0) return GM_ST_CHILD_SPAWN_FAILED;
-    close(tfd);
-    unlink(tmpl);
-    address = tmpl;
+    // The socket lives in a directory of its own that only this user can enter (mkdtemp creates it 0700), so the
+    // name cannot be taken by someone else between its choice and the daemon's bind.
+    char tmpl[] = "/tmp/gpumon-XXXXXX";
+    if (!mkdtemp(tmpl)) return GM_ST_CHILD_SPAWN_FAILED;
+    address = std::string(tmpl) + "/hostengine.sock";
     is_unix = true;
-    pid_t pid = fork();
-    if (pid < 0) return GM_ST_CHILD_SPAWN_FAILED;
-    if (pid == 0) {
-      setpgid(0, 0);  // own process group: terminal signals to the parent do not reach the daemon
-      std::vector<std::string> args = {bin, "--domain-socket", address, "--backend", backend};
-      if (!spec.empty()) {
-        args.push_back("--backend-spec");
-        args.push_back(spec);
-      }
-      std::vector<char*> argv;
-      for (auto& a : args) argv.push_back(const_cast<char*>(a.c_str()));
-      argv.push_back(nullptr);
-      execv(bin.c_str(), argv.data());
-      _exit(127);
+    // posix_spawn, not fork: the caller is an arbitrary, usually multithreaded host (Python with a GPU runtime, a Go
+    // program), and a forked copy of such a process must not run anything but exec.  Own process group: terminal
+    // signals to the parent do not reach the daemon.
+    std::vector<std::string> args = {bin, "--domain-socket", address, "--backend", backend};
+    if (!spec.empty()) {
+      args.push_back("--backend-spec");
+      args.push_back(spec);
+    }
+    std::vector<char*> argv;
+    for (auto& a : args) argv.push_back(const_cast<char*>(a.c_str()));
+    argv.push_back(nullptr);
+    posix_spawnattr_t attr;
+    posix_spawnattr_init(&attr);
+    posix_spawnattr_setflags(&attr, POSIX_SPAWN_SETPGROUP);
+    posix_spawnattr_setpgroup(&attr, 0);
+    pid_t pid = -1;
+    const int rc = posix_spawn(&pid, bin.c_str(), nullptr, &attr, argv.data(), environ);
+    posix_spawnattr_destroy(&attr);
+    if (rc != 0) {
+      GM_LOGE("cannot start %s: %s", bin.c_str(), strerror(rc));
+      rmdir(tmpl);
+      return GM_ST_CHILD_SPAWN_FAILED;
     }
     g.child = pid;
     g.child_socket = address;

@@ -1,6 +1,8 @@
 // LocalEngine core: snapshot cache, groups, field groups, watches, sampler and
 // event threads, discovery, status, introspection.  Health, policy and
 // accounting live in their own translation units.
+#include <sched.h>
+
 #include "engine.h"
 
 #include <algorithm>
@@ -281,15 +283,24 @@ void LocalEngine::publish(GpuState& g, int slot, const SlotValue& v, int64_t ts)
   g.seq.store(s + 2, std::memory_order_release);
 }
 
+// Back off inside a seqlock retry loop: a pause for the first few tries, then give the writer the core.
+static inline void seq_relax(int tries) {
+#if defined(__x86_64__) || defined(__i386__)
+  if (tries < 64) { __builtin_ia32_pause(); return; }
+#endif
+  sched_yield();
+}
+constexpr int kSeqTries = 200000;  // a writer holds the lock for microseconds; this many yields is seconds
+
 bool LocalEngine::read_cell(GpuState& g, int slot, SlotValue* v, int64_t* ts) {
-  for (int tries = 0; tries < 1000000; tries++) {
+  for (int tries = 0; tries < kSeqTries; tries++) {
     uint64_t s1 = g.seq.load(std::memory_order_acquire);
-    if (s1 & 1) continue;
+    if (s1 & 1) { seq_relax(tries); continue; }
     uint64_t bits = g.cells[slot].bits.load(std::memory_order_relaxed);
     int64_t t = g.cells[slot].ts.load(std::memory_order_relaxed);
     uint8_t st = g.cells[slot].status.load(std::memory_order_relaxed);
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (g.seq.load(std::memory_order_relaxed) != s1) continue;
+    if (g.seq.load(std::memory_order_relaxed) != s1) { seq_relax(tries); continue; }
     v->i64 = (int64_t)bits;
     v->status = st;
     if (ts) *ts = t;
@@ -850,9 +861,10 @@ gm_status_t LocalEngine::latest_values(uint32_t gpu, const uint16_t* ids, int n,
   GpuState& g = *gpus_[gpu];
   // One seqlock transaction for the whole batch: the values of one call belong
   // to one published state.
-  for (int tries = 0;; tries++) {
+  bool consistent = false;
+  for (int tries = 0; tries < kSeqTries && !consistent; tries++) {
     uint64_t s1 = g.seq.load(std::memory_order_acquire);
-    if (s1 & 1) continue;
+    if (s1 & 1) { seq_relax(tries); continue; }
     for (int i = 0; i < n; i++) {
       gm_value_t& o = out[i];
       o.field_id = ids[i];
@@ -870,7 +882,15 @@ gm_status_t LocalEngine::latest_values(uint32_t gpu, const uint16_t* ids, int n,
       o.status = g.cells[slot].status.load(std::memory_order_relaxed);
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (g.seq.load(std::memory_order_relaxed) == s1 || tries > 1000000) break;
+    consistent = g.seq.load(std::memory_order_relaxed) == s1;
+    if (!consistent) seq_relax(tries);
+  }
+  if (!consistent) {  // never hand out a batch that may mix two published states
+    for (int i = 0; i < n; i++) {
+      out[i].status = GM_VS_BLANK;
+      out[i].v.i64 = 0;
+    }
+    return GM_ST_STALE_DATA;
   }
   int64_t wall = 0;
   for (int i = 0; i < n; i++) {

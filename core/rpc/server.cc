@@ -128,6 +128,7 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
     case OP_DEVICE_ATTRIBUTES: {
       uint32_t gpu = r.u32();
       gm_device_attributes_t a;
+      memset(&a, 0, sizeof a);  // an error return leaves it untouched: never send stack bytes
       a.version = GM_DEVICE_ATTRIBUTES_VERSION;
       w.i32(engine_->device_attributes(gpu, &a));
       w.pod(a);
@@ -136,6 +137,7 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
     case OP_DEVICE_TOPOLOGY: {
       uint32_t gpu = r.u32();
       gm_topology_t t;
+      memset(&t, 0, sizeof t);  // an error return leaves it untouched: never send stack bytes
       t.version = GM_TOPOLOGY_VERSION;
       w.i32(engine_->device_topology(gpu, &t));
       w.pod(t);
@@ -240,6 +242,7 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
     case OP_DEVICE_STATUS: {
       uint32_t gpu = r.u32();
       gm_device_status_t d;
+      memset(&d, 0, sizeof d);  // an error return leaves it untouched: never send stack bytes
       d.version = GM_DEVICE_STATUS_VERSION;
       w.i32(engine_->device_status(gpu, &d));
       w.pod(d);
@@ -256,6 +259,7 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
     case OP_DEVICE_MODE: {
       uint32_t gpu = r.u32();
       gm_device_mode_t m;
+      memset(&m, 0, sizeof m);  // an error return leaves it untouched: never send stack bytes
       m.version = GM_DEVICE_MODE_VERSION;
       w.i32(engine_->device_mode(gpu, &m));
       w.pod(m);
@@ -330,6 +334,7 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
     case OP_PID_INFO: {
       uint32_t g = r.u32(), pid = r.u32();
       std::unique_ptr<gm_pid_info_t> info(new gm_pid_info_t);
+      memset(info.get(), 0, sizeof *info);  // num_gpus must be 0, not heap garbage, when the engine returns early
       info->version = GM_PID_INFO_VERSION;
       gm_status_t st = engine_->pid_info(g, pid, info.get());
       w.i32(st);
@@ -342,6 +347,7 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
     case OP_INTROSPECT_TOGGLE: return status_only(engine_->introspect_toggle(r.u32() != 0));
     case OP_INTROSPECT: {
       gm_introspect_t in;
+      memset(&in, 0, sizeof in);  // an error return leaves it untouched: never send stack bytes
       in.version = GM_INTROSPECT_VERSION;
       w.i32(engine_->introspect(&in));
       w.pod(in);

@@ -260,6 +260,36 @@ static void test_rpc() {
     });
   for (auto& t : th) t.join();
   CHECK(got >= 4);
+  {
+    // A request the engine refuses before it writes anything (GPU out of range, introspection off) must not bring
+    // back bytes of the server's stack: beyond the version word the reply struct is all zero.
+    gm_status_t st;
+    std::string err;
+    auto eng = make_remote_engine(path, true, 3000, &st, &err);
+    CHECK(eng && st == GM_ST_OK);
+    auto all_zero_after_version = [](const void* p, size_t n) {
+      const unsigned char* b = (const unsigned char*)p;
+      for (size_t i = sizeof(uint32_t); i < n; i++)
+        if (b[i]) return false;
+      return true;
+    };
+    gm_device_attributes_t a;
+    memset(&a, 0xAA, sizeof a);
+    a.version = GM_DEVICE_ATTRIBUTES_VERSION;
+    CHECK(eng->device_attributes(9999, &a) != GM_ST_OK && all_zero_after_version(&a, sizeof a));
+    gm_device_status_t ds;
+    memset(&ds, 0xAA, sizeof ds);
+    ds.version = GM_DEVICE_STATUS_VERSION;
+    CHECK(eng->device_status(9999, &ds) != GM_ST_OK && all_zero_after_version(&ds, sizeof ds));
+    gm_topology_t tp;
+    memset(&tp, 0xAA, sizeof tp);
+    tp.version = GM_TOPOLOGY_VERSION;
+    CHECK(eng->device_topology(9999, &tp) != GM_ST_OK && all_zero_after_version(&tp, sizeof tp));
+    gm_device_mode_t dm;
+    memset(&dm, 0xAA, sizeof dm);
+    dm.version = GM_DEVICE_MODE_VERSION;
+    CHECK(eng->device_mode(9999, &dm) != GM_ST_OK && all_zero_after_version(&dm, sizeof dm));
+  }
   gm_group_t g;
   OK(gm_group_create("c0", &g));  // names of disconnected clients are free again
   OK(gm_server_stop());
