@@ -17,6 +17,8 @@
 struct CliConn {
   std::string connect, backend, backend_spec, hostengine;
   bool is_socket = false, start_hostengine = false;
+  // --health-<level> VALUE: levels of the health checks that differ from the defaults (gm_health_thresholds_t)
+  std::vector<std::pair<std::string, std::string>> health;
 };
 
 static volatile sig_atomic_t g_stop = 0;
@@ -108,6 +110,11 @@ static inline bool parse_conn(std::vector<std::string>& args, CliConn* c) {
     else if (a == "--hostengine-path") { if (!val(&c->hostengine)) return false; }
     else if (a == "--backend") { if (!val(&c->backend)) return false; }
     else if (a == "--backend-spec") { if (!val(&c->backend_spec)) return false; }
+    else if (a.compare(0, 9, "--health-") == 0) {
+      std::string v;
+      if (!val(&v)) return false;
+      c->health.push_back({a.substr(9), v});
+    }
     else rest.push_back(a);
   }
   args.swap(rest);
@@ -124,7 +131,34 @@ static inline gm_status_t cli_init(const CliConn& c) {
   p.backend = c.backend.empty() ? nullptr : c.backend.c_str();
   p.backend_spec = c.backend_spec.empty() ? nullptr : c.backend_spec.c_str();
   p.hostengine_path = c.hostengine.empty() ? nullptr : c.hostengine.c_str();
-  return gm_init(&p);
+  gm_status_t st = gm_init(&p);
+  if (st != GM_ST_OK || c.health.empty()) return st;
+  gm_health_thresholds_t t;
+  memset(&t, 0, sizeof t);
+  t.version = GM_HEALTH_THRESHOLDS_VERSION;
+  if ((st = gm_health_thresholds_get(&t)) == GM_ST_OK) {
+    for (auto& kv : c.health) {
+      const double v = atof(kv.second.c_str());
+      if (kv.first == "hotspot-warn") t.hotspot_warn_c = (int32_t)v;
+      else if (kv.first == "hotspot-fail") t.hotspot_fail_c = (int32_t)v;
+      else if (kv.first == "mem-warn") t.mem_warn_c = (int32_t)v;
+      else if (kv.first == "mem-fail") t.mem_fail_c = (int32_t)v;
+      else if (kv.first == "bad-pages-fail") t.bad_pages_fail = (int32_t)v;
+      else if (kv.first == "ce-burst-warn") t.ce_burst_warn = (int32_t)v;
+      else if (kv.first == "power-over-cap") t.power_over_cap_warn = v;
+      else {
+        fprintf(stderr, "unknown health level --health-%s (hotspot-warn, hotspot-fail, mem-warn, mem-fail, bad-pages-fail, ce-burst-warn, power-over-cap)\n",
+                kv.first.c_str());
+        st = GM_ST_BADPARAM;
+      }
+    }
+    if (st == GM_ST_OK) st = gm_health_thresholds_set(&t);
+  }
+  if (st != GM_ST_OK) {
+    fprintf(stderr, "health levels not accepted: %s\n", gm_strerror(st));
+    gm_shutdown();
+  }
+  return st;
 }
 
 #define CLI_CHECK(expr)                                                        \

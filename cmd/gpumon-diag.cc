@@ -118,10 +118,52 @@ struct Report {
     fprintf(stderr, "\n");
     va_end(ap);
   }
+  // Per-test verdicts, the part of the report the host engine understands (gm_diag_result_t): a failure is kept
+  // as the test's verdict and fails the run; a pass is recorded only where the test has no failure yet, so that a
+  // later clean run replaces an old failure in the engine.
+  struct Verdict {
+    std::string test;
+    uint32_t system;  // GM_HEALTH_WATCH_* bit
+    int health;       // GM_HEALTH_PASS / WARN / FAIL
+    double value;
+    std::string message;
+  };
+  std::vector<Verdict> verdicts;
+  void verdict_fail(const std::string& test, uint32_t system, double value, const char* fmt, ...) __attribute__((format(printf, 5, 6))) {
+    char buf[192];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    fail("%s", buf);
+    for (auto& v : verdicts)
+      if (v.test == test && v.health == GM_HEALTH_FAIL) return;  // the first failure of a test is its verdict
+    for (auto it = verdicts.begin(); it != verdicts.end();)
+      it = it->test == test ? verdicts.erase(it) : it + 1;
+    verdicts.push_back({test, system, GM_HEALTH_FAIL, value, buf});
+  }
+  void verdict_pass(const std::string& test, uint32_t system, double value, const std::string& message) {
+    for (auto& v : verdicts)
+      if (v.test == test) return;
+    verdicts.push_back({test, system, GM_HEALTH_PASS, value, message});
+  }
   // The whole report as one JSON object; `gpu` and `timestamp` let the exporter label and age it.
   std::string document(int gpu) const {
+    std::string vj = "[";
+    for (size_t i = 0; i < verdicts.size(); i++) {
+      const Verdict& v = verdicts[i];
+      char num[64];
+      if (std::isfinite(v.value)) snprintf(num, sizeof num, "%.6g", v.value); else snprintf(num, sizeof num, "null");
+      std::string msg;
+      for (char c : v.message) {
+        if (c == '"' || c == '\\') msg += '\\';
+        msg += (unsigned char)c < 0x20 ? ' ' : c;
+      }
+      vj += std::string(i ? "," : "") + "{\"test\":\"" + v.test + "\",\"system\":" + std::to_string(v.system) + ",\"health\":" +
+            std::to_string(v.health) + ",\"value\":" + num + ",\"message\":\"" + msg + "\"}";
+    }
     return "{\"gpu\":" + std::to_string(gpu) + ",\"timestamp\":" + std::to_string((long long)time(nullptr)) +
-           (js.empty() ? "" : "," + js) + ",\"result\":\"" + (failed ? "fail" : "pass") + "\"}";
+           (js.empty() ? "" : "," + js) + ",\"verdicts\":" + vj + "],\"result\":\"" + (failed ? "fail" : "pass") + "\"}";
   }
   int finish(int gpu, const std::string& publish_path) {
     const std::string doc = document(gpu);
@@ -139,6 +181,16 @@ struct Report {
     return failed ? 1 : 0;
   }
 };
+
+std::string strprintf_local(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+std::string strprintf_local(const char* fmt, ...) {
+  char b[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(b, sizeof b, fmt, ap);
+  va_end(ap);
+  return b;
+}
 
 std::string jnum(double v) {
   if (std::isnan(v) || std::isinf(v)) return "null";
@@ -213,6 +265,7 @@ int cmd_hbm(const Args& a, Report& r) {
          "kernel", "best TB/s", "median", "check");
   std::string obj = "{";
   bool any = false;
+  double worst = 1e30;
   for (int k = 0; k < GMD_STREAM_KERNELS; k++) {
     if (which != "all" && which != kStreamNames[k]) continue;
     gmd_stream_result_t s;
@@ -221,9 +274,12 @@ int cmd_hbm(const Args& a, Report& r) {
     obj += std::string(any ? "," : "") + "\"" + kStreamNames[k] + "\":{\"tbps_best\":" + jnum(s.tbps_best) +
            ",\"tbps_median\":" + jnum(s.tbps_median) + ",\"verified\":" + (s.verified ? "true" : "false") + "}";
     any = true;
-    if (!s.verified) r.fail("stream %s produced wrong data", kStreamNames[k]);
-    if (floor_tbps > 0 && s.tbps_best < floor_tbps) r.fail("stream %s %.3f TB/s is under the %.3f TB/s floor", kStreamNames[k], s.tbps_best, floor_tbps);
+    if (!s.verified) r.verdict_fail("hbm_stream", GM_HEALTH_WATCH_MEM, s.tbps_best, "stream %s produced wrong data", kStreamNames[k]);
+    if (floor_tbps > 0 && s.tbps_best < floor_tbps)
+      r.verdict_fail("hbm_stream", GM_HEALTH_WATCH_MEM, s.tbps_best, "stream %s %.3f TB/s is under the %.3f TB/s floor", kStreamNames[k], s.tbps_best, floor_tbps);
+    worst = std::min(worst, s.tbps_best);
   }
+  if (any) r.verdict_pass("hbm_stream", GM_HEALTH_WATCH_MEM, worst, "every stream kernel verified");
   if (!any) {
     fprintf(stderr, "unknown kernel %s\n", which.c_str());
     return 2;
@@ -274,7 +330,8 @@ int cmd_memtest(const Args& a, Report& r) {
   r.member("memtest", "{\"bytes_tested\":" + std::to_string(m.bytes_tested) + ",\"errors\":" + std::to_string(m.errors) +
                           ",\"patterns\":" + std::to_string(m.patterns_run) + ",\"write_tbps\":" + jnum(m.write_tbps) +
                           ",\"verify_tbps\":" + jnum(m.verify_tbps) + ",\"seconds\":" + jnum(m.seconds) + ",\"log\":" + log + "]}");
-  if (m.errors) r.fail("memtest found %llu bad words", (unsigned long long)m.errors);
+  if (m.errors) r.verdict_fail("memtest", GM_HEALTH_WATCH_MEM, (double)m.errors, "memtest found %llu bad words in %.1f GiB", (unsigned long long)m.errors, m.bytes_tested / 1073741824.0);
+  else r.verdict_pass("memtest", GM_HEALTH_WATCH_MEM, 0, "no bad words");
   return 0;
 }
 
@@ -293,9 +350,10 @@ int cmd_mfma(const Args& a, Report& r) {
     obj += std::string(any ? "," : "") + "\"" + kDtypeNames[dt] + "\":{\"tflops\":" + jnum(m.tflops) + ",\"tflops_best\":" +
            jnum(m.tflops_best) + ",\"clock_mhz\":" + jnum(m.clock_mhz_est) + "}";
     any = true;
-    if (m.verified < 0) r.fail("MFMA %s pipe produced wrong results", kDtypeNames[dt]);
+    if (m.verified < 0) r.verdict_fail("mfma_peak", GM_HEALTH_WATCH_COMPUTE, m.tflops, "MFMA %s pipe produced wrong results", kDtypeNames[dt]);
   }
   if (!any) return 2;
+  r.verdict_pass("mfma_peak", GM_HEALTH_WATCH_COMPUTE, NAN, "matrix pipes ran");
   r.member("mfma_peak", obj + "}");
   return 0;
 }
@@ -533,10 +591,16 @@ int cmd_gemm(const Args& a, Report& r) {
     }
     obj += "}";
     any = true;
+    const std::string test = "gemm_" + name;
     if (g.verified < 0 && !g.sdc_mismatches)
-      r.fail("GEMM %s: sampled entries differ from the fp32 reference (max relative error %.3g, tolerance 4e-3)", name.c_str(), g.max_rel_err);
-    if (g.sdc_mismatches) r.fail("GEMM %s: %llu launches changed their checksum (silent data corruption)", name.c_str(), (unsigned long long)g.sdc_mismatches);
-    if (floor_tf > 0 && g.tflops < floor_tf) r.fail("GEMM %s %.1f TFLOP/s is under the %.1f floor", name.c_str(), g.tflops, floor_tf);
+      r.verdict_fail(test, GM_HEALTH_WATCH_COMPUTE, g.max_rel_err,
+                     "GEMM %s: sampled entries differ from the fp32 reference (max relative error %.3g, tolerance 4e-3)", name.c_str(), g.max_rel_err);
+    if (g.sdc_mismatches)
+      r.verdict_fail(test, GM_HEALTH_WATCH_COMPUTE, (double)g.sdc_mismatches,
+                     "GEMM %s: %llu launches changed their checksum (silent data corruption)", name.c_str(), (unsigned long long)g.sdc_mismatches);
+    if (floor_tf > 0 && g.tflops < floor_tf)
+      r.verdict_fail(test, GM_HEALTH_WATCH_COMPUTE, g.tflops, "GEMM %s %.1f TFLOP/s is under the %.1f floor", name.c_str(), g.tflops, floor_tf);
+    r.verdict_pass(test, GM_HEALTH_WATCH_COMPUTE, g.tflops, strprintf_local("%.1f TFLOP/s, reference and checksums agree", g.tflops));
   }
   r.member("gemm_stress", obj + "}");
   r.member("telemetry", soak.summarize(r));
@@ -587,7 +651,9 @@ int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, std::string
     *js += std::string(i ? "," : "") + "{\"op\":" + jstr(gmd_collective_name(p.op)) + ",\"bytes\":" + std::to_string(p.bytes) +
            ",\"time_us\":" + jnum(p.time_us) + ",\"algbw_gbps\":" + jnum(p.algbw_gbps) + ",\"busbw_gbps\":" + jnum(p.busbw_gbps) +
            ",\"verified\":" + std::to_string(p.verified) + "}";
-    if (p.verified < 0) r.fail("%s of %llu bytes on %d GPUs returned wrong data", gmd_collective_name(p.op), (unsigned long long)p.bytes, w);
+    if (p.verified < 0)
+      r.verdict_fail("rccl", GM_HEALTH_WATCH_XGMI, (double)p.bytes, "%s of %llu bytes on %d GPUs returned wrong data", gmd_collective_name(p.op),
+                     (unsigned long long)p.bytes, w);
   }
   *js += "],\"peak_busbw_gbps\":{";
   r.text("# peak busbw (GB/s):");
@@ -605,7 +671,9 @@ int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, std::string
   if (floor_gbps > 0 && w > 1)
     for (int i = 0; i < GMD_COLL_COUNT; i++)
       if (peak[i] > 0 && peak[i] < floor_gbps)
-        r.fail("%s peaks at %.1f GB/s bus bandwidth on %d GPUs, under the %.1f GB/s floor", gmd_collective_name(i), peak[i], w, floor_gbps);
+        r.verdict_fail("rccl", GM_HEALTH_WATCH_XGMI, peak[i], "%s peaks at %.1f GB/s bus bandwidth on %d GPUs, under the %.1f GB/s floor",
+                       gmd_collective_name(i), peak[i], w, floor_gbps);
+  r.verdict_pass("rccl", GM_HEALTH_WATCH_XGMI, NAN, "every collective returned the right data");
   return 0;
 }
 
@@ -708,7 +776,54 @@ void usage() {
           "  gemm    [-g GPU] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--min-tflops X] [--no-telemetry] [--mfma-counters]\n"
           "  rccl    [--gpus LIST] [--ops LIST] [--min-bytes N] [--max-bytes N] [--factor N] [--iters N] [--scaling] [--no-verify] [--min-busbw GBPS]\n"
           "  p2p     [--gpus LIST] [--bytes N] [--iters N]\n"
-          "  run     -r 1|2|3 [-g GPU]\n");
+          "  run     -r 1|2|3 [-g GPU]\n"
+          "every command: [--json] [--publish FILE] [--submit ENGINE_ADDRESS [--submit-unix]]\n");
+}
+
+// --submit ADDRESS [--submit-unix]: hand the verdicts to a running gpumon-hostengine, where a failed test becomes a
+// health incident of its subsystem and a GPU event (gm_diag_result_submit).  The engine numbers GPUs in PCI order,
+// the compute runtime may not: the GPU is looked up by its PCI address.
+bool submit_verdicts(const Args& a, const Report& r) {
+  const std::string addr = a.str("--submit");
+  gm_init_params_t p;
+  memset(&p, 0, sizeof p);
+  p.version = GM_INIT_PARAMS_VERSION;
+  p.mode = GM_MODE_STANDALONE;
+  p.address = addr.c_str();
+  p.address_is_unix_socket = a.has("--submit-unix") || addr.find('/') != std::string::npos;
+  gm_status_t st = gm_init(&p);
+  if (st != GM_ST_OK) {
+    fprintf(stderr, "error: cannot reach the host engine at %s: %s\n", addr.c_str(), gm_strerror(st));
+    return false;
+  }
+  uint32_t gpu = (uint32_t)a.num("-g", 0), n = 0;
+  gmd_device_info_t d;
+  if (gmd_device_info((int)gpu, &d) == GMD_OK && gm_device_count(&n) == GM_ST_OK)
+    for (uint32_t i = 0; i < n; i++) {
+      gm_device_attributes_t at;
+      memset(&at, 0, sizeof at);
+      at.version = GM_DEVICE_ATTRIBUTES_VERSION;
+      if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, d.pci_bdf) == 0) gpu = i;
+    }
+  bool ok = true;
+  for (auto& v : r.verdicts) {
+    gm_diag_result_t dr;
+    memset(&dr, 0, sizeof dr);
+    dr.version = GM_DIAG_RESULT_VERSION;
+    dr.gpu = gpu;
+    snprintf(dr.test, sizeof dr.test, "%s", v.test.c_str());
+    dr.system = v.system;
+    dr.health = v.health;
+    dr.value = v.value;
+    snprintf(dr.message, sizeof dr.message, "%s", v.message.c_str());
+    st = gm_diag_result_submit(&dr);
+    if (st != GM_ST_OK) {
+      fprintf(stderr, "error: the host engine refused the %s verdict: %s\n", v.test.c_str(), gm_strerror(st));
+      ok = false;
+    }
+  }
+  gm_shutdown();
+  return ok;
 }
 
 }  // namespace
@@ -740,5 +855,7 @@ int main(int argc, char** argv) {
     return 2;
   }
   if (rc) return rc;
-  return r.finish((int)a.num("-g", 0), a.str("--publish"));
+  rc = r.finish((int)a.num("-g", 0), a.str("--publish"));
+  if (rc != 2 && a.has("--submit") && !submit_verdicts(a, r)) return 2;
+  return rc;
 }

@@ -12,12 +12,14 @@
 // bad pages and the performance level are separate sysfs-backed calls that the
 // engine can watch at their own, slower, frequencies.
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <unistd.h>
 
 #include <amd_smi/amdsmi.h>
@@ -69,7 +71,13 @@ namespace {
   X(amdsmi_init_gpu_event_notification, 0)            \
   X(amdsmi_set_gpu_event_notification_mask, 0)        \
   X(amdsmi_get_gpu_event_notification, 0)             \
-  X(amdsmi_stop_gpu_event_notification, 0)
+  X(amdsmi_stop_gpu_event_notification, 0)            \
+  X(amdsmi_get_link_metrics, 0)                        \
+  X(amdsmi_get_gpu_xgmi_link_status, 0)                \
+  X(amdsmi_gpu_xgmi_error_status, 0)                   \
+  X(amdsmi_get_gpu_pci_throughput, 0)                  \
+  X(amdsmi_get_violation_status, 0)                    \
+  X(amdsmi_get_gpu_cper_entries, 0)
 
 struct SmiApi {
   void* lib = nullptr;
@@ -135,8 +143,13 @@ struct Dev {
   uint64_t prev_acc_counter = 0, prev_fw_ts = 0;
   double acc_tick_us = 1000.0;  // PMFW accumulates once per millisecond until measured otherwise
   uint64_t prev_res[5] = {0, 0, 0, 0, 0};
+  uint64_t prev_low = 0, prev_host = 0;  // low-utilisation / below-host-limit residency, worst XCC
   bool have_prev = false;
   bool events_on = false;
+  // RAS records (CPER) cached by the driver: read position, and whether this user may read them at all
+  uint64_t cper_cursor = 0;
+  bool cper_ok = true, cper_primed = false;
+  bool violation_checked = false;
   // CU occupancy comes from the KFD process table, which costs a walk over /proc: read it at most once a
   // second however fast the profiling fields are watched, and not at all where the table is not readable.
   int64_t occupancy_read_mono = 0;
@@ -215,10 +228,17 @@ class AmdSmiBackend : public Backend {
       return rc == AMDSMI_STATUS_NO_PERM ? GM_ST_NO_PERMISSION : GM_ST_INIT_ERROR;
     }
     inited_ = true;
-    return enumerate();
+    gm_status_t est = enumerate();
+    if (est == GM_ST_OK && api_.amdsmi_get_gpu_pci_throughput && !devs_.empty()) {
+      pcie_run_ = true;
+      pcie_thread_ = std::thread([this] { pcie_loop(); });
+    }
+    return est;
   }
 
   void shutdown() override {
+    pcie_run_ = false;
+    if (pcie_thread_.joinable()) pcie_thread_.join();  // before mu_: the loop takes it once a round
     std::lock_guard<std::mutex> l(mu_);
     if (!inited_) return;
     for (auto& d : devs_)
@@ -334,7 +354,15 @@ class AmdSmiBackend : public Backend {
     p.hops = (uint32_t)hops;
     if (type == AMDSMI_LINK_TYPE_XGMI) {
       p.link = GM_LINK_XGMI;
-      p.num_links = 1;  // MI355X nodes are fully connected: one link per peer, seven peers
+      // Parallel links to this peer = physical links whose far end carries the peer's PCI address (the count the
+      // reference takes from the NVLink remote PCI info, bindings/go/nvml/nvml.go:539-568).  Where the platform
+      // hides the far end (virtualised hosts report an all-ones address) an xGMI neighbour has at least one.
+      std::vector<XgmiLink> links;
+      uint32_t to_peer = 0;
+      if (xgmi_links_locked(a, &links) == GM_ST_OK)
+        for (auto& l : links)
+          if (l.state != 0 && !l.peer_bdf.empty() && l.peer_bdf == b.st.pci_bdf) to_peer++;
+      p.num_links = to_peer ? to_peer : 1;
     } else if (type == AMDSMI_LINK_TYPE_PCIE) {
       p.link = classify_pcie(a.st.pci_bdf, b.st.pci_bdf, a.st.numa_node, b.st.numa_node);
     } else if (type == AMDSMI_LINK_TYPE_INTERNAL) {
@@ -356,14 +384,192 @@ class AmdSmiBackend : public Backend {
     return GM_ST_OK;
   }
 
+  bool delivers_ras_events() override { return cper_any_; }
+
+  gm_status_t xgmi_links(uint32_t gpu, std::vector<XgmiLink>* out) override {
+    out->clear();
+    if (gpu >= devs_.size()) return GM_ST_BADPARAM;
+    return xgmi_links_locked(devs_[gpu], out);
+  }
+
+  // Link table from amdsmi_get_link_metrics (far end, rate, traffic) joined with the per-link state; on libraries
+  // without it, state and traffic from the metrics table and no far end.
+  gm_status_t xgmi_links_locked(Dev& d, std::vector<XgmiLink>* out) {
+    out->clear();
+    int state[GM_MAX_XGMI_LINKS];
+    for (int i = 0; i < GM_MAX_XGMI_LINKS; i++) state[i] = -1;
+    bool have_state = false;
+    if (api_.amdsmi_get_gpu_xgmi_link_status) {
+      amdsmi_xgmi_link_status_t ls;
+      memset(&ls, 0, sizeof ls);
+      if (api_.amdsmi_get_gpu_xgmi_link_status(d.h, &ls) == AMDSMI_STATUS_SUCCESS) {
+        have_state = true;
+        for (uint32_t i = 0; i < ls.total_links && i < GM_MAX_XGMI_LINKS && i < AMDSMI_MAX_NUM_XGMI_LINKS; i++)
+          state[i] = ls.status[i] == AMDSMI_XGMI_LINK_UP ? 1 : ls.status[i] == AMDSMI_XGMI_LINK_DOWN ? 0 : -1;
+      }
+    }
+    amdsmi_gpu_metrics_t m;
+    memset(&m, 0xff, sizeof m);
+    const bool have_metrics = api_.amdsmi_get_gpu_metrics_info(d.h, &m) == AMDSMI_STATUS_SUCCESS;
+    if (!have_state && have_metrics)
+      for (int i = 0; i < GM_MAX_XGMI_LINKS; i++) {
+        const uint16_t ls = m.xgmi_link_status[i];
+        if (valid(ls) && ls != AMDSMI_XGMI_LINK_DISABLE) state[i] = ls == AMDSMI_XGMI_LINK_UP ? 1 : 0, have_state = true;
+      }
+    std::unique_ptr<amdsmi_link_metrics_t> lm;
+    if (api_.amdsmi_get_link_metrics) {
+      lm.reset(new amdsmi_link_metrics_t);
+      memset(lm.get(), 0, sizeof *lm);
+      if (api_.amdsmi_get_link_metrics(d.h, lm.get()) != AMDSMI_STATUS_SUCCESS) lm.reset();
+    }
+    if (!have_state && !lm) return GM_ST_NOT_SUPPORTED;
+    for (int i = 0; i < GM_MAX_XGMI_LINKS; i++) {
+      XgmiLink l;
+      l.index = (uint32_t)i;
+      l.state = state[i];
+      if (have_metrics) {
+        if (valid(m.xgmi_read_data_acc[i])) l.rx_kb = (int64_t)m.xgmi_read_data_acc[i];
+        if (valid(m.xgmi_write_data_acc[i])) l.tx_kb = (int64_t)m.xgmi_write_data_acc[i];
+      }
+      // Some library builds leave num_links at 0 and still fill the entries: go by the entry's link type.
+      if (lm && (uint32_t)i < AMDSMI_MAX_NUM_XGMI_PHYSICAL_LINK && lm->links[i].link_type == AMDSMI_LINK_TYPE_XGMI) {
+        const auto& e = lm->links[i];
+        if (e.bit_rate) l.bit_rate_gbps = e.bit_rate;
+        if (e.max_bandwidth) l.max_bandwidth_gbps = e.max_bandwidth;
+        if (l.rx_kb < 0) l.rx_kb = (int64_t)e.read;
+        if (l.tx_kb < 0) l.tx_kb = (int64_t)e.write;
+        // An all-ones address is the library's "unknown" (seen on virtualised single-GPU hosts).
+        if (e.bdf.as_uint != ~0ull && e.bdf.as_uint != 0)
+          l.peer_bdf = strprintf("%04llx:%02x:%02x.%x", (unsigned long long)e.bdf.domain_number, (unsigned)e.bdf.bus_number,
+                                 (unsigned)e.bdf.device_number, (unsigned)e.bdf.function_number);
+      }
+      if (l.state < 0 && l.peer_bdf.empty() && l.rx_kb <= 0 && l.tx_kb <= 0) continue;  // not a wired link
+      out->push_back(l);
+    }
+    return GM_ST_OK;
+  }
+
+  // One-time cross-check of the residency accumulators this backend reads from the metrics table against the
+  // library's own violation report (amdsmi_get_violation_status).  That call sleeps 100 ms between two reads of
+  // its own, so it runs once, on a thread of its own, never in the sampler.
+  void check_violation_source(Dev& d) {
+    if (!api_.amdsmi_get_violation_status) return;
+    amdsmi_processor_handle h = d.h;
+    const uint32_t index = d.st.index;
+    auto fn_status = api_.amdsmi_get_violation_status;
+    auto fn_metrics = api_.amdsmi_get_gpu_metrics_info;
+    std::thread([h, index, fn_status, fn_metrics] {
+      std::unique_ptr<amdsmi_violation_status_t> v(new amdsmi_violation_status_t);
+      memset(v.get(), 0xff, sizeof *v);
+      if (fn_status(h, v.get()) != AMDSMI_STATUS_SUCCESS) return;
+      amdsmi_gpu_metrics_t m;
+      memset(&m, 0xff, sizeof m);
+      if (fn_metrics(h, &m) != AMDSMI_STATUS_SUCCESS) return;
+      auto close_to = [](uint64_t a, uint64_t b) { return a <= b && b - a <= b / 100 + 2000; };  // the table was read later
+      const bool counter_ok = !valid(v->acc_counter) || !valid(m.accumulation_counter) || close_to(v->acc_counter, m.accumulation_counter);
+      const bool ppt_ok = !valid(v->acc_ppt_pwr) || !valid(m.ppt_residency_acc) || close_to(v->acc_ppt_pwr, m.ppt_residency_acc);
+      if (counter_ok && ppt_ok) GM_LOGI("amdsmi: GPU %u residency accumulators agree with the library's violation report", index);
+      else GM_LOGW("amdsmi: GPU %u residency accumulators differ from the library's violation report (counter %llu vs %llu, ppt %llu vs %llu)",
+                   index, (unsigned long long)v->acc_counter, (unsigned long long)m.accumulation_counter,
+                   (unsigned long long)v->acc_ppt_pwr, (unsigned long long)m.ppt_residency_acc);
+    }).detach();
+  }
+
+  // ---- PCIe TX / RX ---------------------------------------------------------------
+  // amdsmi_get_gpu_pci_throughput measures for one second inside the driver, so it cannot sit in the sampler.  A
+  // thread of its own asks every GPU in turn, at most every five seconds, and integrates the measured rates into
+  // two cumulative KB counters per GPU (what the contract metrics are).  Hosts that do not offer the measurement
+  // answer the first round with "not supported" at once; the thread then ends and the fields stay blank.
+  struct PcieAcc {
+    double tx_kb = 0, rx_kb = 0;
+    int64_t last_mono = 0;
+    uint64_t readings = 0;
+  };
+  void pcie_loop() {
+    while (pcie_run_) {
+      std::vector<std::pair<amdsmi_processor_handle, uint64_t>> targets;
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        if (!inited_) break;
+        for (auto& d : devs_) targets.push_back({d.h, d.bdf_key});
+      }
+      const int64_t pass_t0 = monotonic_us();
+      bool any = false;
+      for (auto& t : targets) {
+        if (!pcie_run_) break;
+        uint64_t sent = 0, received = 0, max_pkt = 0;
+        if (api_.amdsmi_get_gpu_pci_throughput(t.first, &sent, &received, &max_pkt) != AMDSMI_STATUS_SUCCESS) continue;
+        any = true;
+        const int64_t now = monotonic_us();
+        std::lock_guard<std::mutex> pl(pcie_mu_);
+        PcieAcc& a = pcie_acc_[t.second];
+        const double seconds = a.last_mono ? std::min(60.0, (double)(now - a.last_mono) / 1e6) : 1.0;
+        a.tx_kb += (double)sent / 1024.0 * seconds;
+        a.rx_kb += (double)received / 1024.0 * seconds;
+        a.last_mono = now;
+        a.readings++;
+      }
+      if (!any) {
+        GM_LOGI("amdsmi: PCIe throughput is not measured on this host; dcgm_pcie_tx/rx_throughput stay blank");
+        break;
+      }
+      for (int64_t left = 5000000 - (monotonic_us() - pass_t0); left > 0 && pcie_run_; left -= 100000) usleep(100000);
+    }
+  }
+
+  // ---- RAS records -----------------------------------------------------------------
+  // New CPER entries of fatal / uncorrected severity become RAS events.  Entries that were already in the driver's
+  // cache when monitoring started are skipped: they are history, not news.
+  void poll_cper(std::vector<DeviceEvent>* out) {
+    if (!api_.amdsmi_get_gpu_cper_entries) return;
+    const int64_t now = monotonic_us();
+    if (cper_read_mono_ && now - cper_read_mono_ < 5000000) return;
+    cper_read_mono_ = now;
+    std::lock_guard<std::mutex> l(mu_);
+    if (!inited_) return;
+    std::vector<char> buf(64 << 10);
+    amdsmi_cper_hdr_t* hdrs[64];
+    bool any_ok = false;
+    for (auto& d : devs_) {
+      if (!d.cper_ok) continue;
+      for (int round = 0; round < 16; round++) {
+        uint64_t size = buf.size(), count = 64;
+        const uint32_t mask = (1u << AMDSMI_CPER_SEV_FATAL) | (1u << AMDSMI_CPER_SEV_NON_FATAL_UNCORRECTED);
+        amdsmi_status_t rc = api_.amdsmi_get_gpu_cper_entries(d.h, mask, buf.data(), &size, hdrs, &count, &d.cper_cursor);
+        if (rc != AMDSMI_STATUS_SUCCESS && rc != AMDSMI_STATUS_MORE_DATA) {
+          if (rc == AMDSMI_STATUS_NO_PERM || rc == AMDSMI_STATUS_NOT_SUPPORTED || rc == AMDSMI_STATUS_NOT_YET_IMPLEMENTED ||
+              rc == AMDSMI_STATUS_FILE_NOT_FOUND) {
+            d.cper_ok = false;
+            GM_LOGI("amdsmi: RAS records (CPER) of GPU %u are not readable (%s); RAS events come from counter steps", d.st.index, errstr(rc));
+          }
+          break;
+        }
+        any_ok = true;
+        if (d.cper_primed)
+          for (uint64_t i = 0; i < count && i < 64; i++) {
+            DeviceEvent e;
+            e.gpu = d.st.index;
+            e.ts_us = now_us();
+            e.code = hdrs[i]->error_severity == AMDSMI_CPER_SEV_FATAL ? GM_EVENT_RAS_UE : GM_EVENT_RAS_POISON;
+            e.message = strprintf("RAS record %.8s: %s error", hdrs[i]->record_id,
+                                  hdrs[i]->error_severity == AMDSMI_CPER_SEV_FATAL ? "fatal" : "uncorrected (deferred)");
+            out->push_back(e);
+          }
+        if (rc != AMDSMI_STATUS_MORE_DATA) break;
+      }
+      d.cper_primed = true;
+    }
+    cper_any_ = any_ok;
+  }
+
   gm_status_t poll_events(int timeout_ms, std::vector<DeviceEvent>* out) override {
-    if (!api_.amdsmi_init_gpu_event_notification || !api_.amdsmi_get_gpu_event_notification ||
-        !api_.amdsmi_set_gpu_event_notification_mask)
-      return GM_ST_NOT_SUPPORTED;
+    const bool have_channel_api = api_.amdsmi_init_gpu_event_notification && api_.amdsmi_get_gpu_event_notification &&
+                                  api_.amdsmi_set_gpu_event_notification_mask;
+    poll_cper(out);
     {
       std::lock_guard<std::mutex> l(mu_);
       if (!inited_) return GM_ST_UNINITIALIZED;
-      if (!events_tried_) {
+      if (!events_tried_ && have_channel_api) {
         events_tried_ = true;
         uint64_t mask = AMDSMI_EVENT_MASK_FROM_INDEX(AMDSMI_EVT_NOTIF_VMFAULT) |
                         AMDSMI_EVENT_MASK_FROM_INDEX(AMDSMI_EVT_NOTIF_THERMAL_THROTTLE) |
@@ -377,7 +583,13 @@ class AmdSmiBackend : public Backend {
           events_any_ = events_any_ || d.events_on;
         }
       }
-      if (!events_any_) return GM_ST_NOT_SUPPORTED;
+      if (!events_any_) {
+        if (!cper_any_) return GM_ST_NOT_SUPPORTED;  // neither an event channel nor readable RAS records
+      }
+    }
+    if (!events_any_) {  // RAS records only: pace the caller's loop ourselves
+      usleep((useconds_t)std::max(1, timeout_ms) * 1000);
+      return GM_ST_OK;
     }
     amdsmi_evt_notification_data_t data[16];
     uint32_t n = 16;
@@ -663,10 +875,20 @@ class AmdSmiBackend : public Backend {
       if (valid(m.current_socket_power)) out->set_d(GM_FI_POWER_USAGE, m.current_socket_power);
       else if (valid(m.average_socket_power)) out->set_d(GM_FI_POWER_USAGE, m.average_socket_power);
       else out->set_blank(GM_FI_POWER_USAGE, GM_VS_NOT_SUPPORTED);
-      // The metrics table carries one combined PCIe accumulator, no TX/RX split:
-      // the two directional counters stay blank rather than carry a guess.
-      out->set_blank(GM_FI_PCIE_TX_KB, GM_VS_NOT_SUPPORTED);
-      out->set_blank(GM_FI_PCIE_RX_KB, GM_VS_NOT_SUPPORTED);
+      // The metrics table carries one combined PCIe accumulator, no TX/RX split.  The directional counters come
+      // from the driver's one-second throughput measurement where the host offers it (pcie_loop), and stay blank
+      // otherwise rather than carry a guess.
+      {
+        std::lock_guard<std::mutex> pl(pcie_mu_);
+        auto it = pcie_acc_.find(d.bdf_key);
+        if (it != pcie_acc_.end() && it->second.readings) {
+          out->set_i(GM_FI_PCIE_TX_KB, (int64_t)it->second.tx_kb);
+          out->set_i(GM_FI_PCIE_RX_KB, (int64_t)it->second.rx_kb);
+        } else {
+          out->set_blank(GM_FI_PCIE_TX_KB, GM_VS_NOT_SUPPORTED);
+          out->set_blank(GM_FI_PCIE_RX_KB, GM_VS_NOT_SUPPORTED);
+        }
+      }
       set64(GM_FI_PCIE_REPLAY_COUNTER, m.pcie_replay_count_acc);
       if (valid(m.pcie_bandwidth_inst)) out->set_i(GM_FI_PCIE_BW_INST, (int64_t)(m.pcie_bandwidth_inst / 8));  // Mb/s -> MB/s
       else out->set_blank(GM_FI_PCIE_BW_INST, GM_VS_NOT_SUPPORTED);
@@ -724,6 +946,10 @@ class AmdSmiBackend : public Backend {
     }
 
     if (sources & SRC_VIOLATION) {
+      if (!d.violation_checked) {
+        d.violation_checked = true;
+        check_violation_source(d);
+      }
       // Residency accumulators count firmware accumulation cycles; the cycle
       // length is measured from the firmware timestamp (10 ns units).
       if (valid(m.accumulation_counter) && valid(m.firmware_timestamp) && d.have_prev &&
@@ -740,16 +966,20 @@ class AmdSmiBackend : public Backend {
       if (valid(res[3]) || valid(res[4])) out->set_i(GM_FI_BOARD_LIMIT_VIOLATION, us((valid(res[3]) ? res[3] : 0) + (valid(res[4]) ? res[4] : 0)));
       else out->set_blank(GM_FI_BOARD_LIMIT_VIOLATION, GM_VS_NOT_SUPPORTED);
       out->set_blank(GM_FI_SYNC_BOOST_VIOLATION, GM_VS_NOT_SUPPORTED);
-      uint64_t low = 0, host = 0;
-      bool any_low = false, any_host = false;
+      // Low-utilisation and below-host-limit residency are kept per XCC.  The contract metric is a duration of the
+      // DEVICE ("throttling duration ... (in us)"), which can never advance faster than the wall clock: take the
+      // XCC that spent longest in the state, not the sum over XCCs (eight of them would count eight seconds a second).
+      uint64_t low_xcc[AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC], host_xcc[AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC];
       for (int p = 0; p < AMDSMI_MAX_NUM_XCP; p++)
         for (int x = 0; x < AMDSMI_MAX_NUM_XCC; x++) {
-          uint64_t a = m.xcp_stats[p].gfx_low_utilization_acc[x];
           uint64_t b = m.xcp_stats[p].gfx_below_host_limit_total_acc[x];
           if (!valid(b)) b = m.xcp_stats[p].gfx_below_host_limit_acc[x];
-          if (valid(a)) { low += a; any_low = true; }
-          if (valid(b)) { host += b; any_host = true; }
+          low_xcc[p * AMDSMI_MAX_NUM_XCC + x] = m.xcp_stats[p].gfx_low_utilization_acc[x];
+          host_xcc[p * AMDSMI_MAX_NUM_XCC + x] = b;
         }
+      uint64_t low = 0, host = 0;
+      const bool any_low = device_residency(low_xcc, AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC, &low);
+      const bool any_host = device_residency(host_xcc, AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC, &host);
       if (any_low) out->set_i(GM_FI_LOW_UTIL_VIOLATION, us(low)); else out->set_blank(GM_FI_LOW_UTIL_VIOLATION, GM_VS_NOT_SUPPORTED);
       if (any_host) out->set_i(GM_FI_RELIABILITY_VIOLATION, us(host)); else out->set_blank(GM_FI_RELIABILITY_VIOLATION, GM_VS_NOT_SUPPORTED);
       // Active reasons = accumulators that moved since the previous sample.
@@ -759,7 +989,11 @@ class AmdSmiBackend : public Backend {
                                           GM_THROTTLE_VR_THERMAL, GM_THROTTLE_PROCHOT};
         for (int i = 0; i < 5; i++)
           if (valid(res[i]) && res[i] > d.prev_res[i]) bits |= bit_of[i];
+        if (any_low && low > d.prev_low) bits |= GM_THROTTLE_LOW_UTIL;
+        if (any_host && host > d.prev_host) bits |= GM_THROTTLE_HOST_LIMIT;
       }
+      d.prev_low = any_low ? low : 0;
+      d.prev_host = any_host ? host : 0;
       out->set_i(GM_FI_THROTTLE_STATUS, bits);
       for (int i = 0; i < 5; i++) d.prev_res[i] = valid(res[i]) ? res[i] : 0;
       d.prev_acc_counter = valid(m.accumulation_counter) ? m.accumulation_counter : 0;
@@ -936,9 +1170,22 @@ class AmdSmiBackend : public Backend {
         ok = true;
       }
     }
-    // Replay / recovery counters of the link layer are not exposed for xGMI.
+    // The link layer exposes no replay / recovery COUNTERS for xGMI, only a latched error state; the two
+    // contract counters stay blank and the state is its own field.
     out->set_blank(GM_FI_XGMI_REPLAY_ERRORS, GM_VS_NOT_SUPPORTED);
     out->set_blank(GM_FI_XGMI_RECOVERY_ERRORS, GM_VS_NOT_SUPPORTED);
+    if (api_.amdsmi_gpu_xgmi_error_status) {
+      amdsmi_xgmi_status_t xs = AMDSMI_XGMI_STATUS_NO_ERRORS;
+      amdsmi_status_t r = api_.amdsmi_gpu_xgmi_error_status(d.h, &xs);
+      if (r == AMDSMI_STATUS_SUCCESS) {
+        out->set_i(GM_FI_XGMI_ERROR_STATUS, xs == AMDSMI_XGMI_STATUS_NO_ERRORS ? 0 : xs == AMDSMI_XGMI_STATUS_ERROR ? 1 : 2);
+        ok = true;
+      } else {
+        out->set_blank(GM_FI_XGMI_ERROR_STATUS, blank_reason(r));
+      }
+    } else {
+      out->set_blank(GM_FI_XGMI_ERROR_STATUS, GM_VS_NOT_SUPPORTED);
+    }
     out->blank_untouched(SRC_ECC, blank_reason(rc == AMDSMI_STATUS_SUCCESS ? AMDSMI_STATUS_NOT_SUPPORTED : rc));
     return ok;
   }
@@ -1002,6 +1249,12 @@ class AmdSmiBackend : public Backend {
   SmiApi api_;
   std::mutex mu_;
   bool inited_ = false, events_tried_ = false, events_any_ = false;
+  std::atomic<bool> cper_any_{false};
+  int64_t cper_read_mono_ = 0;
+  std::mutex pcie_mu_;
+  std::map<uint64_t, PcieAcc> pcie_acc_;  // by PCI address: survives a re-enumeration
+  std::atomic<bool> pcie_run_{false};
+  std::thread pcie_thread_;
   ProfApi prof_;
   bool prof_tried_ = false, prof_warned_ = false;
   std::vector<Dev> devs_;

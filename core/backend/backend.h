@@ -105,12 +105,34 @@ struct PeerLink {
   bool p2p_accessible = false;
 };
 
+// One physical xGMI link (see gm_xgmi_link_t).
+struct XgmiLink {
+  uint32_t index = 0;
+  int state = -1;        // 1 up, 0 down, -1 not wired / not reported
+  std::string peer_bdf;  // empty when unknown
+  int64_t bit_rate_gbps = -1, max_bandwidth_gbps = -1, rx_kb = -1, tx_kb = -1;
+};
+
 struct DeviceEvent {
   uint32_t gpu = 0;
   uint32_t code = GM_EVENT_NONE;
   int64_t ts_us = 0;
   std::string message;
 };
+
+// Per-device duration from per-XCC residency accumulators (~0 = not reported): the XCC that spent longest in the
+// state.  A sum would let a "duration" of the device advance several seconds per wall-clock second.
+inline bool device_residency(const uint64_t* per_xcc, int n, uint64_t* out) {
+  bool any = false;
+  uint64_t worst = 0;
+  for (int i = 0; i < n; i++) {
+    if (per_xcc[i] == ~0ull) continue;
+    worst = any ? (per_xcc[i] > worst ? per_xcc[i] : worst) : per_xcc[i];
+    any = true;
+  }
+  if (any) *out = worst;
+  return any;
+}
 
 class Backend {
  public:
@@ -124,9 +146,17 @@ class Backend {
   virtual gm_status_t sample(uint32_t gpu, uint32_t sources, Sample* out) = 0;
   virtual gm_status_t processes(uint32_t gpu, std::vector<ProcSample>* out) = 0;
   virtual gm_status_t peer_link(uint32_t gpu, uint32_t peer, PeerLink* out) = 0;
+  // Every physical xGMI link of the GPU, in the index order of the per-link telemetry fields.
+  virtual gm_status_t xgmi_links(uint32_t gpu, std::vector<XgmiLink>* out) {
+    (void)gpu, (void)out;
+    return GM_ST_NOT_SUPPORTED;
+  }
   // Waits up to timeout_ms for driver events; returns GM_ST_NOT_SUPPORTED when
   // the backend has no event channel (the engine then stops polling).
   virtual gm_status_t poll_events(int timeout_ms, std::vector<DeviceEvent>* out) = 0;
+  // True when poll_events itself reports RAS errors (from the driver's error records); the engine then does not
+  // derive them from steps of the error counters, which would say everything twice.
+  virtual bool delivers_ras_events() { return false; }
   // Backend-specific control channel (fake backend scripting).
   virtual gm_status_t control(const std::string& command) { (void)command; return GM_ST_NOT_SUPPORTED; }
   // Re-enumerate after a GPU reset.

@@ -34,7 +34,11 @@ struct FakeGpu {
   int64_t bad_ce = 0, bad_ue = 0, bad_pending = 0;
   int64_t energy_mj = 0, pcie_tx_kb = 0, pcie_rx_kb = 0, pcie_replay = 0;
   int64_t xgmi_rx[GM_MAX_XGMI_LINKS], xgmi_tx[GM_MAX_XGMI_LINKS];
-  int64_t viol_power = 0, viol_thermal = 0, viol_board = 0, viol_low = 0, viol_rel = 0;
+  int64_t viol_power = 0, viol_thermal = 0, viol_board = 0, viol_rel = 0;
+  uint64_t viol_low_xcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per-XCC low-utilisation residency (us): every idle XCC accrues wall time
+  int64_t viol_seen_mono = 0;
+  int64_t prev_viol[5] = {0, 0, 0, 0, 0};  // power, thermal, board, low, reliability at the previous sample
+  int xgmi_error_state = 0;
   int64_t vram_used_mib = 283;
   std::vector<ProcSample> procs;
 };
@@ -233,6 +237,7 @@ class FakeBackend : public Backend {
       out->set_i(GM_FI_XGMI_DATA_ERRORS, g.ecc_ue[4]);
       out->set_blank(GM_FI_XGMI_REPLAY_ERRORS, GM_VS_NOT_SUPPORTED);
       out->set_blank(GM_FI_XGMI_RECOVERY_ERRORS, GM_VS_NOT_SUPPORTED);
+      out->set_i(GM_FI_XGMI_ERROR_STATUS, g.xgmi_error_state);
     }
     if (ok & SRC_BAD_PAGES) {
       out->set_i(GM_FI_BAD_PAGES_CE, g.bad_ce);
@@ -252,9 +257,24 @@ class FakeBackend : public Backend {
       out->set_i(GM_FI_THERMAL_VIOLATION, g.viol_thermal);
       out->set_blank(GM_FI_SYNC_BOOST_VIOLATION, GM_VS_NOT_SUPPORTED);
       out->set_i(GM_FI_BOARD_LIMIT_VIOLATION, g.viol_board);
-      out->set_i(GM_FI_LOW_UTIL_VIOLATION, g.viol_low);
+      // An idle GPU sits in the low-utilisation state on all eight XCCs at once; the device duration is the worst
+      // XCC's, which is what keeps it under the wall clock.
+      const int64_t mono = monotonic_us();
+      if (g.viol_seen_mono && load < 5 && !steady_)
+        for (int x = 0; x < 8; x++) g.viol_low_xcc[x] += (uint64_t)((double)(mono - g.viol_seen_mono) * (1.0 - 0.01 * x));
+      g.viol_seen_mono = mono;
+      uint64_t low = 0;
+      device_residency(g.viol_low_xcc, 8, &low);
+      out->set_i(GM_FI_LOW_UTIL_VIOLATION, (int64_t)low);
       out->set_i(GM_FI_RELIABILITY_VIOLATION, g.viol_rel);
-      out->set_i(GM_FI_THROTTLE_STATUS, 0);
+      const int64_t cur[5] = {g.viol_power, g.viol_thermal, g.viol_board, (int64_t)low, g.viol_rel};
+      static const int64_t bit_of[5] = {GM_THROTTLE_POWER, GM_THROTTLE_THERMAL, GM_THROTTLE_PROCHOT, GM_THROTTLE_LOW_UTIL, GM_THROTTLE_HOST_LIMIT};
+      int64_t bits = 0;
+      for (int i = 0; i < 5; i++) {
+        if (g.n > 1 && cur[i] > g.prev_viol[i]) bits |= bit_of[i];
+        g.prev_viol[i] = cur[i];
+      }
+      out->set_i(GM_FI_THROTTLE_STATUS, bits);
     }
     if (ok & SRC_PROF) {
       out->set_d(GM_FI_PROF_GR_ENGINE_ACTIVE, load);
@@ -321,6 +341,29 @@ class FakeBackend : public Backend {
     }
     p.p2p_accessible = true;
     *out = p;
+    return GM_ST_OK;
+  }
+
+  // Fully connected hive of up to eight: link l of GPU g goes to the l-th other GPU in index order.
+  static uint32_t peer_of(uint32_t gpu, uint32_t link) { return link < gpu ? link : link + 1; }
+
+  gm_status_t xgmi_links(uint32_t gpu, std::vector<XgmiLink>* out) override {
+    std::lock_guard<std::mutex> l(mu_);
+    out->clear();
+    if (gpu >= gpus_.size()) return GM_ST_BADPARAM;
+    if (topology_unsupported_) return GM_ST_NOT_SUPPORTED;
+    const uint32_t hive0 = gpu / 8 * 8, hive_n = (uint32_t)std::min<size_t>(8, gpus_.size() - hive0);
+    for (uint32_t i = 0; i + 1 < hive_n && i < 7; i++) {
+      XgmiLink k;
+      k.index = i;
+      k.state = gpus_[gpu].link_up[i] ? 1 : 0;
+      k.peer_bdf = gpus_[hive0 + peer_of(gpu - hive0, i)].st.pci_bdf;
+      k.bit_rate_gbps = 38;
+      k.max_bandwidth_gbps = 608;
+      k.rx_kb = gpus_[gpu].xgmi_rx[i];
+      k.tx_kb = gpus_[gpu].xgmi_tx[i];
+      out->push_back(k);
+    }
     return GM_ST_OK;
   }
 
@@ -420,8 +463,11 @@ class FakeBackend : public Backend {
         g.pcie_replay += geti("count", 1);
       } else if (verb == "violation") {
         g.viol_power += geti("power", 0); g.viol_thermal += geti("thermal", 0);
-        g.viol_board += geti("board", 0); g.viol_low += geti("low_util", 0);
+        g.viol_board += geti("board", 0);
+        for (int x = 0; x < 8; x++) g.viol_low_xcc[x] += (uint64_t)geti("low_util", 0);
         g.viol_rel += geti("reliability", 0);
+      } else if (verb == "xgmi_error") {
+        g.xgmi_error_state = (int)geti("state", 1);
       } else if (verb == "link_down" || verb == "link_up") {
         long lk = geti("link", -1);
         if (lk < 0 || lk >= GM_MAX_XGMI_LINKS) return GM_ST_BADPARAM;

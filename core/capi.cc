@@ -364,6 +364,19 @@ gm_status_t gm_device_topology(uint32_t gpu, gm_topology_t* out) {
   return e->device_topology(gpu, out);
 }
 
+gm_status_t gm_xgmi_links(uint32_t gpu, gm_xgmi_link_t* out, int* n) {
+  REQUIRE_ENGINE();
+  if (!n) return GM_ST_BADPARAM;
+  std::vector<gm_xgmi_link_t> v;
+  gm_status_t st = e->xgmi_links(gpu, &v);
+  if (st != GM_ST_OK) return st;
+  int cap = *n;
+  *n = (int)v.size();
+  if (cap < (int)v.size() || (!out && !v.empty())) return GM_ST_INSUFFICIENT_SIZE;
+  for (size_t i = 0; i < v.size(); i++) out[i] = v[i];
+  return GM_ST_OK;
+}
+
 const char* gm_link_type_name(int32_t link, uint32_t hops) { return link_type_name(link, hops); }
 const char* gm_link_type_description(int32_t link) { return link_type_description(link); }
 
@@ -485,6 +498,33 @@ gm_status_t gm_health_check(gm_group_t g, gm_health_response_t* out, int* n) {
   if (out && *n > 0 && out[0].version != GM_HEALTH_RESPONSE_VERSION) return GM_ST_VER_MISMATCH;
   std::vector<gm_health_response_t> v;
   gm_status_t st = e->health_check(g, &v);
+  if (st != GM_ST_OK) return st;
+  int cap = *n;
+  *n = (int)v.size();
+  if (cap < (int)v.size() || (!out && !v.empty())) return GM_ST_INSUFFICIENT_SIZE;
+  for (size_t i = 0; i < v.size(); i++) out[i] = v[i];
+  return GM_ST_OK;
+}
+gm_status_t gm_health_thresholds_set(const gm_health_thresholds_t* t) {
+  REQUIRE_ENGINE();
+  if (!t) return GM_ST_BADPARAM;
+  return e->health_thresholds_set(*t);
+}
+gm_status_t gm_health_thresholds_get(gm_health_thresholds_t* t) {
+  REQUIRE_ENGINE();
+  if (!t) return GM_ST_BADPARAM;
+  return e->health_thresholds_get(t);
+}
+gm_status_t gm_diag_result_submit(const gm_diag_result_t* r) {
+  REQUIRE_ENGINE();
+  if (!r) return GM_ST_BADPARAM;
+  return e->diag_submit(*r);
+}
+gm_status_t gm_diag_results(uint32_t gpu, gm_diag_result_t* out, int* n) {
+  REQUIRE_ENGINE();
+  if (!n) return GM_ST_BADPARAM;
+  std::vector<gm_diag_result_t> v;
+  gm_status_t st = e->diag_results(gpu, &v);
   if (st != GM_ST_OK) return st;
   int cap = *n;
   *n = (int)v.size();
@@ -624,7 +664,8 @@ gm_status_t gm_event_register(gm_event_set_t es, uint32_t gpu, uint64_t event_ma
   }
   if (!event_mask)  // every critical event: the XidCriticalError analog
     event_mask = (1ull << GM_EVENT_VMFAULT) | (1ull << GM_EVENT_GPU_PRE_RESET) | (1ull << GM_EVENT_GPU_POST_RESET) |
-                 (1ull << GM_EVENT_RAS_UE) | (1ull << GM_EVENT_RAS_POISON) | (1ull << GM_EVENT_RING_HANG);
+                 (1ull << GM_EVENT_RAS_UE) | (1ull << GM_EVENT_RAS_POISON) | (1ull << GM_EVENT_RING_HANG) |
+                 (1ull << GM_EVENT_DIAG_FAIL);
   std::lock_guard<std::mutex> l(s->mu);
   s->mask[gpu] |= event_mask;
   s->registered = true;

@@ -120,6 +120,7 @@ const char* event_code_name(uint32_t code) {
     case GM_EVENT_RAS_UE: return "RAS uncorrectable error";
     case GM_EVENT_RAS_POISON: return "RAS poison consumed";
     case GM_EVENT_RING_HANG: return "ring hang";
+    case GM_EVENT_DIAG_FAIL: return "diagnostic failed";
     case GM_EVENT_PROCESS_START: return "process start";
     case GM_EVENT_PROCESS_END: return "process end";
   }
@@ -214,7 +215,9 @@ void Notifier::run() {
 
 // ------------------------------------------------------------ LocalEngine --
 
-LocalEngine::LocalEngine(std::unique_ptr<Backend> backend) : backend_(std::move(backend)) {}
+LocalEngine::LocalEngine(std::unique_ptr<Backend> backend) : backend_(std::move(backend)) {
+  thresholds_ = health_default_thresholds();
+}
 
 LocalEngine::~LocalEngine() { stop(); }
 
@@ -604,6 +607,31 @@ void LocalEngine::sample_gpu(uint32_t gpu, uint32_t sources, const std::vector<u
     sample.blank_untouched(sources, GM_VS_ERROR);
   }
   const int nslots = field_count();
+  // RAS events for platforms that do not hand them out: a step of the uncorrectable / deferred totals between two
+  // ECC samples is the error having happened (the reference waits for the driver's XID event instead,
+  // bindings/go/nvml/bindings.go:68-146).
+  std::vector<DeviceEvent> synthesized;
+  if ((sources & SRC_ECC) && !backend_->delivers_ras_events()) {
+    struct { uint16_t id; int64_t* prev; uint32_t code; const char* what; } steps[] = {
+        {GM_FI_ECC_UE_VOLATILE, &g.prev_ue, GM_EVENT_RAS_UE, "uncorrectable"},
+        {GM_FI_ECC_DEFERRED, &g.prev_deferred, GM_EVENT_RAS_POISON, "deferred"}};
+    for (auto& st2 : steps) {
+      const int slot = field_slot(st2.id);
+      if (slot < 0 || !sample.touched[slot] || sample.v[slot].status != GM_VS_OK) continue;
+      const int64_t cur = sample.v[slot].i64;
+      if (*st2.prev >= 0 && cur > *st2.prev) {
+        DeviceEvent e;
+        e.gpu = gpu;
+        e.code = st2.code;
+        e.ts_us = now_wall;
+        e.message = strprintf("RAS: %lld %s error(s) since the last sample (total %lld)", (long long)(cur - *st2.prev), st2.what,
+                              (long long)cur);  // fits the 63 characters of a violation payload
+        synthesized.push_back(e);
+      }
+      *st2.prev = cur;
+    }
+  }
+  {
   std::lock_guard<std::mutex> hl(g.hist_mu);
   {
     std::lock_guard<std::mutex> wl(g.write_mu);
@@ -638,6 +666,8 @@ void LocalEngine::sample_gpu(uint32_t gpu, uint32_t sources, const std::vector<u
       while (!h.empty() && h.front().ts_us < now_wall - sw.keep_age_us) h.pop_front();
     if (h.size() > 400000) h.pop_front();  // hard cap: 100 Hz x 300 s plus slack
   }
+  }  // hist_mu
+  for (auto& e : synthesized) handle_event(e);
 }
 
 void LocalEngine::sampler_loop() {
@@ -791,10 +821,19 @@ void LocalEngine::handle_event(const DeviceEvent& e) {
 }
 
 gm_status_t LocalEngine::event_subscribe(EventFn fn, uint32_t* sub) {
-  std::lock_guard<std::mutex> l(state_mu_);
-  *sub = next_sub_++;
-  event_subs_[*sub] = std::move(fn);
-  return GM_ST_OK;
+  {
+    std::lock_guard<std::mutex> l(state_mu_);
+    *sub = next_sub_++;
+    event_subs_[*sub] = std::move(fn);
+    // RAS events are derived from steps of the error totals where the platform does not hand them out: somebody
+    // listening for events is a reason to keep those totals sampled.
+    if (!backend_->delivers_ras_events()) {
+      std::vector<uint32_t> all;
+      for (uint32_t i = 0; i < gpus_.size(); i++) all.push_back(i);
+      ensure_internal_watch("ras", all, {GM_FI_ECC_UE_VOLATILE, GM_FI_ECC_DEFERRED}, GM_DEFAULT_UPDATE_FREQ_US);
+    }
+  }
+  return update_all(true);  // the totals seen now are the baseline: only later errors are events
 }
 
 gm_status_t LocalEngine::event_unsubscribe(uint32_t sub) {
@@ -803,6 +842,70 @@ gm_status_t LocalEngine::event_unsubscribe(uint32_t sub) {
     if (!event_subs_.erase(sub)) return GM_ST_NOT_FOUND;
   }
   notifier_.drain();  // no callback of this subscription runs after we return
+  return GM_ST_OK;
+}
+
+// ------------------------------------------------------- links, diagnostics --
+
+gm_status_t LocalEngine::xgmi_links(uint32_t gpu, std::vector<gm_xgmi_link_t>* out) {
+  out->clear();
+  if (gpu >= gpus_.size()) return GM_ST_BADPARAM;
+  std::vector<XgmiLink> links;
+  gm_status_t st = backend_->xgmi_links(gpu, &links);
+  if (st != GM_ST_OK) return st;
+  for (auto& l : links) {
+    gm_xgmi_link_t o;
+    memset(&o, 0, sizeof o);
+    o.link = l.index;
+    o.state = l.state;
+    o.peer_gpu = -1;
+    if (!l.peer_bdf.empty())
+      for (size_t p = 0; p < gpus_.size(); p++)
+        if (p != gpu && gpus_[p]->st.pci_bdf == l.peer_bdf) o.peer_gpu = (int32_t)p;
+    copy_str(o.peer_bdf, l.peer_bdf);
+    o.bit_rate_gbps = l.bit_rate_gbps;
+    o.max_bandwidth_gbps = l.max_bandwidth_gbps;
+    o.rx_kb = l.rx_kb;
+    o.tx_kb = l.tx_kb;
+    out->push_back(o);
+  }
+  return GM_ST_OK;
+}
+
+gm_status_t LocalEngine::diag_submit(const gm_diag_result_t& r) {
+  if (r.version != GM_DIAG_RESULT_VERSION) return GM_ST_VER_MISMATCH;
+  if (r.gpu >= gpus_.size() || !r.test[0] || !memchr(r.test, 0, sizeof r.test) || !memchr(r.message, 0, sizeof r.message))
+    return GM_ST_BADPARAM;
+  if (r.health != GM_HEALTH_PASS && r.health != GM_HEALTH_WARN && r.health != GM_HEALTH_FAIL) return GM_ST_BADPARAM;
+  if (!r.system || (r.system & (r.system - 1)) || !(r.system & GM_HEALTH_WATCH_ALL)) return GM_ST_BADPARAM;  // exactly one system
+  gm_diag_result_t kept = r;
+  if (!kept.ts_us) kept.ts_us = now_us();
+  GpuState& g = *gpus_[r.gpu];
+  bool news;
+  {
+    std::lock_guard<std::mutex> l(g.hist_mu);
+    auto it = g.diag.find(kept.test);
+    // The same verdict handed in again (a report file read twice) is not a second failure.
+    news = it == g.diag.end() || it->second.ts_us != kept.ts_us || it->second.health != kept.health;
+    g.diag[kept.test] = kept;
+  }
+  if (news && kept.health == GM_HEALTH_FAIL) {
+    DeviceEvent e;
+    e.gpu = r.gpu;
+    e.code = GM_EVENT_DIAG_FAIL;
+    e.ts_us = kept.ts_us;
+    e.message = strprintf("diagnostic %s failed: %s", kept.test, kept.message);
+    handle_event(e);
+  }
+  return GM_ST_OK;
+}
+
+gm_status_t LocalEngine::diag_results(uint32_t gpu, std::vector<gm_diag_result_t>* out) {
+  out->clear();
+  if (gpu >= gpus_.size()) return GM_ST_BADPARAM;
+  GpuState& g = *gpus_[gpu];
+  std::lock_guard<std::mutex> l(g.hist_mu);
+  for (auto& kv : g.diag) out->push_back(kv.second);
   return GM_ST_OK;
 }
 

@@ -75,6 +75,12 @@ class Engine {
 
   virtual gm_status_t event_subscribe(EventFn fn, uint32_t* sub) = 0;
   virtual gm_status_t event_unsubscribe(uint32_t sub) = 0;
+
+  virtual gm_status_t xgmi_links(uint32_t gpu, std::vector<gm_xgmi_link_t>* out) = 0;
+  virtual gm_status_t health_thresholds_set(const gm_health_thresholds_t& t) = 0;
+  virtual gm_status_t health_thresholds_get(gm_health_thresholds_t* t) = 0;
+  virtual gm_status_t diag_submit(const gm_diag_result_t& r) = 0;
+  virtual gm_status_t diag_results(uint32_t gpu, std::vector<gm_diag_result_t>* out) = 0;
 };
 
 // ----------------------------------------------------------------------------
@@ -149,6 +155,11 @@ class LocalEngine : public Engine {
   gm_status_t introspect(gm_introspect_t* out) override;
   gm_status_t event_subscribe(EventFn fn, uint32_t* sub) override;
   gm_status_t event_unsubscribe(uint32_t sub) override;
+  gm_status_t xgmi_links(uint32_t gpu, std::vector<gm_xgmi_link_t>* out) override;
+  gm_status_t health_thresholds_set(const gm_health_thresholds_t& t) override;
+  gm_status_t health_thresholds_get(gm_health_thresholds_t* t) override;
+  gm_status_t diag_submit(const gm_diag_result_t& r) override;
+  gm_status_t diag_results(uint32_t gpu, std::vector<gm_diag_result_t>* out) override;
 
  private:
   // ---- snapshot (seqlock) ---------------------------------------------------
@@ -178,6 +189,9 @@ class LocalEngine : public Engine {
     std::map<int, Hold> holds;                     // hist_mu
     std::vector<int64_t> critical_event_ts;        // hist_mu
     uint32_t last_event_code = 0;
+    // RAS events synthesised from counter steps: the totals seen by the previous ECC sample (-1 = none yet)
+    int64_t prev_ue = -1, prev_deferred = -1;      // sampler thread only
+    std::map<std::string, gm_diag_result_t> diag;  // hist_mu; latest result per test
   };
 
   struct Watch {
@@ -272,6 +286,7 @@ class LocalEngine : public Engine {
   std::map<gm_policy_reg_t, std::shared_ptr<PolicyReg>> policy_regs_;
   std::map<uint32_t, PidWatch> pid_watch_;  // by gpu
   std::map<uint32_t, EventFn> event_subs_;
+  gm_health_thresholds_t thresholds_;
 
   std::mutex wake_mu_;
   std::condition_variable wake_cv_, cycle_cv_;
@@ -302,6 +317,7 @@ const char* health_result_name(int32_t health);
 const char* policy_condition_name(uint32_t condition);
 const char* event_code_name(uint32_t code);
 const char* status_string(gm_status_t st);
+gm_health_thresholds_t health_default_thresholds();
 void fill_attributes(const GpuStatic& s, gm_device_attributes_t* out);
 // Value of a static (read-once) field out of the attribute cache.
 void static_value(const GpuStatic& s, uint16_t id, gm_value_t* out);

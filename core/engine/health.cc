@@ -17,7 +17,7 @@ namespace {
 const uint16_t kHealthFields[] = {
     GM_FI_PCIE_REPLAY_COUNTER, GM_FI_PCIE_NAK_SENT, GM_FI_PCIE_NAK_RCVD, GM_FI_PCIE_L0_TO_RECOVERY,
     GM_FI_DEV_PCIE_GEN, GM_FI_DEV_PCIE_WIDTH,
-    GM_FI_XGMI_LINKS_DOWN, GM_FI_XGMI_CRC_ERRORS, GM_FI_XGMI_DATA_ERRORS,
+    GM_FI_XGMI_LINKS_DOWN, GM_FI_XGMI_CRC_ERRORS, GM_FI_XGMI_DATA_ERRORS, GM_FI_XGMI_ERROR_STATUS,
     GM_FI_XGMI_LINK_STATUS_0, GM_FI_XGMI_LINK_STATUS_0 + 1, GM_FI_XGMI_LINK_STATUS_0 + 2, GM_FI_XGMI_LINK_STATUS_0 + 3,
     GM_FI_XGMI_LINK_STATUS_0 + 4, GM_FI_XGMI_LINK_STATUS_0 + 5, GM_FI_XGMI_LINK_STATUS_0 + 6, GM_FI_XGMI_LINK_STATUS_0 + 7,
     GM_FI_ECC_UMC_CE, GM_FI_ECC_UMC_UE, GM_FI_ECC_GFX_CE, GM_FI_ECC_GFX_UE, GM_FI_ECC_SDMA_UE, GM_FI_ECC_MMHUB_UE,
@@ -26,12 +26,41 @@ const uint16_t kHealthFields[] = {
     GM_FI_GPU_TEMP, GM_FI_MEM_TEMP, GM_FI_THERMAL_VIOLATION, GM_FI_POWER_VIOLATION, GM_FI_BOARD_LIMIT_VIOLATION,
     GM_FI_POWER_USAGE, GM_FI_DEV_POWER_CAP, GM_FI_THROTTLE_STATUS};
 
-// Level thresholds for MI355X-class parts (°C).
-const int64_t kHotspotWarn = 100, kHotspotFail = 110, kMemWarn = 95, kMemFail = 105;
-const int64_t kBadPagesFail = 256;  // the RAS bad-page table fills up around this many entries
-const int64_t kCeBurstWarn = 100;   // correctable errors between two checks
+// Level thresholds for MI355X-class parts (degrees C, counts); gm_health_thresholds_set replaces them.
+gm_health_thresholds_t default_thresholds() {
+  gm_health_thresholds_t t;
+  memset(&t, 0, sizeof t);
+  t.version = GM_HEALTH_THRESHOLDS_VERSION;
+  t.hotspot_warn_c = 100;
+  t.hotspot_fail_c = 110;
+  t.mem_warn_c = 95;
+  t.mem_fail_c = 105;
+  t.bad_pages_fail = 256;  // the RAS bad-page table fills up around this many entries
+  t.ce_burst_warn = 100;   // correctable errors between two checks
+  t.power_over_cap_warn = 1.10;
+  return t;
+}
 
 }  // namespace
+
+gm_health_thresholds_t health_default_thresholds() { return default_thresholds(); }
+
+gm_status_t LocalEngine::health_thresholds_set(const gm_health_thresholds_t& t) {
+  if (t.version != GM_HEALTH_THRESHOLDS_VERSION) return GM_ST_VER_MISMATCH;
+  if (t.hotspot_warn_c <= 0 || t.hotspot_fail_c < t.hotspot_warn_c || t.mem_warn_c <= 0 || t.mem_fail_c < t.mem_warn_c ||
+      t.bad_pages_fail <= 0 || t.ce_burst_warn <= 0 || !(t.power_over_cap_warn >= 1.0))
+    return GM_ST_BADPARAM;
+  std::lock_guard<std::mutex> l(state_mu_);
+  thresholds_ = t;
+  return GM_ST_OK;
+}
+
+gm_status_t LocalEngine::health_thresholds_get(gm_health_thresholds_t* t) {
+  if (t->version != GM_HEALTH_THRESHOLDS_VERSION) return GM_ST_VER_MISMATCH;
+  std::lock_guard<std::mutex> l(state_mu_);
+  *t = thresholds_;
+  return GM_ST_OK;
+}
 
 gm_status_t LocalEngine::health_set(gm_group_t g, uint32_t systems) {
   if (systems & ~GM_HEALTH_WATCH_ALL) return GM_ST_BADPARAM;
@@ -64,13 +93,17 @@ gm_status_t LocalEngine::health_check(gm_group_t g, std::vector<gm_health_respon
   out->clear();
   std::vector<uint32_t> gp;
   uint32_t systems = 0;
+  gm_health_thresholds_t th;
   {
     std::lock_guard<std::mutex> l(state_mu_);
     gm_status_t st = resolve_group(g, &gp);
     if (st != GM_ST_OK) return st;
     auto it = groups_.find(g);
     if (it != groups_.end()) systems = it->second.health_systems;
+    th = thresholds_;
   }
+  const int64_t kHotspotWarn = th.hotspot_warn_c, kHotspotFail = th.hotspot_fail_c, kMemWarn = th.mem_warn_c, kMemFail = th.mem_fail_c;
+  const int64_t kBadPagesFail = th.bad_pages_fail, kCeBurstWarn = th.ce_burst_warn;
   if (!systems) return GM_ST_NOT_CONFIGURED;
 
   for (uint32_t gpu : gp) {
@@ -129,6 +162,8 @@ gm_status_t LocalEngine::health_check(gm_group_t g, std::vector<gm_health_respon
     for (int l = 0; l < GM_MAX_XGMI_LINKS; l++)
       if (get_i(gpu, GM_FI_XGMI_LINK_STATUS_0 + l, &v) && v == 0)
         incident(GM_HEALTH_WATCH_XGMI, GM_HEALTH_FAIL, strprintf("xGMI link %d is down.", l));
+    if (get_i(gpu, GM_FI_XGMI_ERROR_STATUS, &v) && v > 0)
+      incident(GM_HEALTH_WATCH_XGMI, GM_HEALTH_WARN, v > 1 ? "The xGMI link layer has latched several errors." : "The xGMI link layer has latched an error.");
     if ((v = delta(GM_FI_XGMI_DATA_ERRORS)) > 0)
       incident(GM_HEALTH_WATCH_XGMI, GM_HEALTH_FAIL, strprintf("Detected %lld uncorrectable xGMI errors since the last check.", (long long)v));
     if ((v = delta(GM_FI_XGMI_CRC_ERRORS)) > 0)
@@ -182,8 +217,9 @@ gm_status_t LocalEngine::health_check(gm_group_t g, std::vector<gm_health_respon
       incident(GM_HEALTH_WATCH_POWER, GM_HEALTH_WARN, strprintf("PROCHOT / VR limits throttled clocks for %lld us since the last check.", (long long)v));
     {
       double p, cap;
-      if (get_d(gpu, GM_FI_POWER_USAGE, &p) && get_d(gpu, GM_FI_DEV_POWER_CAP, &cap) && cap > 0 && p > cap * 1.10)
-        incident(GM_HEALTH_WATCH_POWER, GM_HEALTH_WARN, strprintf("Socket power %.0f W exceeds the %.0f W cap by more than 10%%.", p, cap));
+      if (get_d(gpu, GM_FI_POWER_USAGE, &p) && get_d(gpu, GM_FI_DEV_POWER_CAP, &cap) && cap > 0 && p > cap * th.power_over_cap_warn)
+        incident(GM_HEALTH_WATCH_POWER, GM_HEALTH_WARN,
+                 strprintf("Socket power %.0f W exceeds the %.0f W cap by more than %.0f%%.", p, cap, (th.power_over_cap_warn - 1.0) * 100.0));
     }
 
     // ---- driver / RAS events
@@ -205,6 +241,15 @@ gm_status_t LocalEngine::health_check(gm_group_t g, std::vector<gm_health_respon
         incident(GM_HEALTH_WATCH_DRIVER, GM_HEALTH_WARN,
                  strprintf("%llu device-library calls failed since the last check.", (unsigned long long)(errs - base.backend_errors)));
       next.backend_errors = errs;
+    }
+
+    // ---- active diagnostics: the latest result of every test that did not pass stays an incident of its system
+    {
+      GpuState& gs = *gpus_[gpu];
+      std::lock_guard<std::mutex> l(gs.hist_mu);
+      for (auto& kv : gs.diag)
+        if (kv.second.health != GM_HEALTH_PASS)
+          incident(kv.second.system, kv.second.health, strprintf("Diagnostic %s: %s", kv.second.test, kv.second.message));
     }
 
     // ---- firmware

@@ -10,6 +10,8 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstring>
 #include <map>
 #include <mutex>
 
@@ -114,7 +116,32 @@ void parse_report(const Json& r, Families* f) {
 std::mutex g_mu;
 std::map<std::string, CachedReport> g_cache;
 
-void load(const std::string& file, Families* merged) {
+// The per-test verdicts of a report, as the engine takes them.
+void submit_verdicts(const Json& r, Engine* engine) {
+  const Json* vs = r.get("verdicts");
+  if (!engine || !vs || vs->type != Json::ARR) return;
+  for (auto& v : vs->arr) {
+    if (v.type != Json::OBJ) continue;
+    gm_diag_result_t d;
+    memset(&d, 0, sizeof d);
+    d.version = GM_DIAG_RESULT_VERSION;
+    d.gpu = (uint32_t)num(r.get("gpu"), 0);
+    const Json* t = v.get("test");
+    const Json* m = v.get("message");
+    if (!t || t->type != Json::STR || t->str.empty()) continue;
+    copy_str(d.test, t->str);
+    if (m && m->type == Json::STR) copy_str(d.message, m->str);
+    d.system = (uint32_t)num(v.get("system"), 0);
+    d.health = (int32_t)num(v.get("health"), 0);
+    const Json* val = v.get("value");
+    d.value = val && val->type == Json::NUM ? val->num : std::nan("");
+    d.ts_us = (int64_t)(num(r.get("timestamp"), 0) * 1e6);  // the same report read again is the same verdict
+    gm_status_t st = engine->diag_submit(d);
+    if (st != GM_ST_OK) GM_LOGW("exporter: diagnostics verdict %s of GPU %u not accepted (%d)", d.test, d.gpu, (int)st);
+  }
+}
+
+void load(const std::string& file, Families* merged, Engine* engine) {
   struct stat st;
   if (stat(file.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return;
   const int64_t mt = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
@@ -124,8 +151,10 @@ void load(const std::string& file, Families* merged) {
     c.fams.clear();
     std::string text;
     Json j;
-    if (read_file(file, &text) && json_parse(text, &j) && j.type == Json::OBJ) parse_report(j, &c.fams);
-    else GM_LOGW("exporter: %s is not a diagnostics report", file.c_str());
+    if (read_file(file, &text) && json_parse(text, &j) && j.type == Json::OBJ) {
+      parse_report(j, &c.fams);
+      submit_verdicts(j, engine);
+    } else GM_LOGW("exporter: %s is not a diagnostics report", file.c_str());
   }
   for (auto& kv : c.fams) {
     auto& dst = (*merged)[kv.first];
@@ -135,7 +164,7 @@ void load(const std::string& file, Families* merged) {
 
 }  // namespace
 
-void render_diag_results(const std::string& path, std::string* out) {
+void render_diag_results(const std::string& path, std::string* out, Engine* engine) {
   if (path.empty()) return;
   std::lock_guard<std::mutex> l(g_mu);
   Families merged;
@@ -151,9 +180,9 @@ void render_diag_results(const std::string& path, std::string* out) {
       closedir(d);
     }
     std::sort(files.begin(), files.end());
-    for (auto& f : files) load(f, &merged);
+    for (auto& f : files) load(f, &merged, engine);
   } else {
-    load(path, &merged);
+    load(path, &merged, engine);
   }
   for (auto& kv : merged) {
     *out += strprintf("# HELP %s %s\n# TYPE %s gauge\n", kv.first.c_str(), help_of(kv.first), kv.first.c_str());

@@ -16,6 +16,7 @@ struct Member {
   uint16_t field;
   const char* label;  // extra label name or nullptr
   std::string label_value;
+  int link = -1;  // xGMI link index when the label is "link"
 };
 struct Family {
   std::string name, help;
@@ -46,6 +47,7 @@ std::vector<Family> build_families(bool profiling, bool extras) {
     m.label = f->extra_label;
     if (f->extra_label)
       m.label_value = !strcmp(f->extra_label, "block") ? kBlockNames[f->extra_index] : strprintf("%d", f->extra_index);
+    if (f->extra_label && !strcmp(f->extra_label, "link") && f->extra_index >= 0 && f->extra_index < GM_MAX_XGMI_LINKS) m.link = f->extra_index;
     fam->members.push_back(m);
   };
   for (uint16_t id : contract_fields()) {
@@ -129,6 +131,7 @@ gm_status_t Exporter::init() {
   uuids_.clear();
   bdfs_.clear();
   partitions_.clear();
+  link_peer_.clear();
   for (uint32_t g : gpus_) {
     gm_device_attributes_t a;
     a.version = GM_DEVICE_ATTRIBUTES_VERSION;
@@ -147,6 +150,13 @@ gm_status_t Exporter::init() {
       if (engine_->latest_values(g, &fid, 1, &v) == GM_ST_OK && v.status == GM_VS_OK) part = (int)v.v.i64;
     }
     partitions_.push_back(part);
+    // Who sits at the far end of each xGMI link: the `peer` label of the per-link series.
+    std::vector<int> peers(GM_MAX_XGMI_LINKS, -1);
+    std::vector<gm_xgmi_link_t> links;
+    if (engine_->xgmi_links(g, &links) == GM_ST_OK)
+      for (auto& l : links)
+        if (l.link < GM_MAX_XGMI_LINKS) peers[l.link] = l.peer_gpu;
+    link_peer_.push_back(peers);
   }
   fields_.clear();
   for (auto& fam : build_families(cfg_.profiling, cfg_.amd_extras))
@@ -304,6 +314,7 @@ void Exporter::render(std::string* out) {
       *out += "=\"";
       *out += m.label_value;
       *out += "\"";
+      if (m.link >= 0 && link_peer_[g][(size_t)m.link] >= 0) *out += strprintf(",peer=\"%d\"", link_peer_[g][(size_t)m.link]);
     }
     *out += podl[g];
     *out += "} ";
@@ -356,7 +367,7 @@ void Exporter::render(std::string* out) {
         }
   }
   if (cfg_.self_metrics) render_self(out);
-  if (!cfg_.diag_results_path.empty()) render_diag_results(cfg_.diag_results_path, out);
+  if (!cfg_.diag_results_path.empty()) render_diag_results(cfg_.diag_results_path, out, engine_);
   last_render_us_ = monotonic_us() - t0;
 }
 

@@ -80,6 +80,7 @@ class Exporter {
   std::vector<uint32_t> gpus_;
   std::vector<std::string> uuids_, bdfs_;
   std::vector<int> partitions_;  // compute-partition index per exported entry; -1 = GPU is not partitioned (no label)
+  std::vector<std::vector<int>> link_peer_;  // per exported entry: GPU index at the far end of xGMI link l, -1 = unknown
   std::vector<uint16_t> fields_;  // every field id fetched per GPU
   gm_group_t group_ = 0;
   gm_field_group_t fg_ = 0;
@@ -108,7 +109,9 @@ class Exporter {
 // server.go:40-71) under /dcgm/... with /gpumon/... aliases.  Returns false
 // when the path is not a REST route.
 // Appends the gpumon_diag_* families for the report file (or directory of *.json reports) at `path`.
-void render_diag_results(const std::string& path, std::string* out);
+// Also hands the verdicts of every report that is new or has changed to `engine` (may be null), where a failed
+// test becomes a health incident and a GPU event.
+void render_diag_results(const std::string& path, std::string* out, Engine* engine = nullptr);
 bool handle_rest(Engine* engine, const HttpRequest& req, HttpResponse* resp);
 
 }  // namespace gpumon

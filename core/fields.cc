@@ -134,6 +134,7 @@ std::vector<FieldDef> build_table() {
     {GM_FI_XGMI_LINK_SPEED,      I64, SRC_METRICS, "xgmi_link_speed", "Gbps", GAUGE, 2, "gpumon_xgmi_link_speed", "xGMI link speed (in Gbps per lane).", nullptr, 0},
     {GM_FI_XGMI_LINKS_UP,        I64, SRC_METRICS, "xgmi_links_up", "", GAUGE, 2, "gpumon_xgmi_links_up", "Number of xGMI links that are up.", nullptr, 0},
     {GM_FI_XGMI_LINKS_DOWN,      I64, SRC_METRICS, "xgmi_links_down", "", GAUGE, 2, "gpumon_xgmi_links_down", "Number of xGMI links that are down.", nullptr, 0},
+    {GM_FI_XGMI_ERROR_STATUS,    I64, SRC_ECC,     "xgmi_error_status", "", GAUGE, 2, "gpumon_xgmi_error_status", "xGMI link-layer error state (0 = no errors, 1 = an error, 2 = several errors).", nullptr, 0},
 
     // ---- profiling-class --------------------------------------------------
     {GM_FI_PROF_GR_ENGINE_ACTIVE, DBL, SRC_PROF, "prof_gr_engine_active", "%", GAUGE, 1, "dcgm_fi_prof_gr_engine_active", "Ratio of time the graphics engine is active (in %).", nullptr, 0},

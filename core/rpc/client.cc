@@ -201,6 +201,44 @@ class RemoteEngine : public Engine {
     if (cnt) r.raw(out->data(), cnt * sizeof(gm_health_response_t));
     return r.ok() ? st : GM_ST_VER_MISMATCH;
   }
+  template <typename T>
+  gm_status_t call_list(uint32_t op, const WireWriter& w, std::vector<T>* out, uint32_t max_count) {
+    std::string rep;
+    gm_status_t st = call(op, w, &rep);
+    WireReader r(rep.data(), rep.size());
+    uint32_t cnt = r.u32(), sz = r.u32();
+    out->clear();
+    if (!r.ok()) return st != GM_ST_OK ? st : GM_ST_CONNECTION_NOT_VALID;
+    if (sz != sizeof(T) || cnt > max_count) return GM_ST_VER_MISMATCH;
+    out->resize(cnt);
+    if (cnt) r.raw(out->data(), cnt * sizeof(T));
+    return r.ok() ? st : GM_ST_VER_MISMATCH;
+  }
+  gm_status_t xgmi_links(uint32_t gpu, std::vector<gm_xgmi_link_t>* out) override {
+    WireWriter w;
+    w.u32(gpu);
+    return call_list(OP_XGMI_LINKS, w, out, 64);
+  }
+  gm_status_t health_thresholds_set(const gm_health_thresholds_t& t) override {
+    WireWriter w;
+    w.pod(t);
+    return call(OP_HEALTH_THRESHOLDS_SET, w, nullptr);
+  }
+  gm_status_t health_thresholds_get(gm_health_thresholds_t* t) override {
+    if (t->version != GM_HEALTH_THRESHOLDS_VERSION) return GM_ST_VER_MISMATCH;
+    WireWriter w;
+    return call_pod(OP_HEALTH_THRESHOLDS_GET, w, t);
+  }
+  gm_status_t diag_submit(const gm_diag_result_t& d) override {
+    WireWriter w;
+    w.pod(d);
+    return call(OP_DIAG_SUBMIT, w, nullptr);
+  }
+  gm_status_t diag_results(uint32_t gpu, std::vector<gm_diag_result_t>* out) override {
+    WireWriter w;
+    w.u32(gpu);
+    return call_list(OP_DIAG_RESULTS, w, out, 256);
+  }
   gm_status_t policy_set(gm_group_t g, const gm_policy_t& p) override {
     WireWriter w;
     w.u32(g); w.pod(p);

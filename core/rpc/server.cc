@@ -284,6 +284,42 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
       if (!out.empty()) w.raw(out.data(), out.size() * sizeof(gm_health_response_t));
       return w.data();
     }
+    case OP_XGMI_LINKS: {
+      uint32_t gpu = r.u32();
+      std::vector<gm_xgmi_link_t> out;
+      w.i32(engine_->xgmi_links(gpu, &out));
+      w.u32((uint32_t)out.size());
+      w.u32((uint32_t)sizeof(gm_xgmi_link_t));
+      if (!out.empty()) w.raw(out.data(), out.size() * sizeof(gm_xgmi_link_t));
+      return w.data();
+    }
+    case OP_HEALTH_THRESHOLDS_SET: {
+      gm_health_thresholds_t t;
+      if (!r.pod(&t)) return status_only(GM_ST_VER_MISMATCH);
+      return status_only(engine_->health_thresholds_set(t));
+    }
+    case OP_HEALTH_THRESHOLDS_GET: {
+      gm_health_thresholds_t t;
+      memset(&t, 0, sizeof t);
+      t.version = GM_HEALTH_THRESHOLDS_VERSION;
+      w.i32(engine_->health_thresholds_get(&t));
+      w.pod(t);
+      return w.data();
+    }
+    case OP_DIAG_SUBMIT: {
+      gm_diag_result_t d;
+      if (!r.pod(&d)) return status_only(GM_ST_VER_MISMATCH);
+      return status_only(engine_->diag_submit(d));
+    }
+    case OP_DIAG_RESULTS: {
+      uint32_t gpu = r.u32();
+      std::vector<gm_diag_result_t> out;
+      w.i32(engine_->diag_results(gpu, &out));
+      w.u32((uint32_t)out.size());
+      w.u32((uint32_t)sizeof(gm_diag_result_t));
+      if (!out.empty()) w.raw(out.data(), out.size() * sizeof(gm_diag_result_t));
+      return w.data();
+    }
     case OP_POLICY_SET: {
       uint32_t g = r.u32();
       gm_policy_t p;

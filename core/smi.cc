@@ -198,6 +198,37 @@ gm_status_t gm_smi_device_processes(uint32_t gpu, gm_process_t* out, int* n) {
   return (int)ps.size() > cap ? GM_ST_INSUFFICIENT_SIZE : GM_ST_OK;
 }
 
+gm_status_t gm_smi_xgmi_links(uint32_t gpu, gm_xgmi_link_t* out, int* n) {
+  Smi& s = S();
+  SMI_READY(s);
+  if (!n || gpu >= s.st.size()) return GM_ST_BADPARAM;
+  std::vector<XgmiLink> links;
+  gm_status_t st;
+  {
+    std::lock_guard<std::mutex> c(s.call_mu);
+    st = s.be->xgmi_links(gpu, &links);
+  }
+  if (st != GM_ST_OK) return st;
+  const int cap = *n;
+  *n = (int)links.size();
+  if (cap < (int)links.size() || (!out && !links.empty())) return GM_ST_INSUFFICIENT_SIZE;
+  for (size_t i = 0; i < links.size(); i++) {
+    gm_xgmi_link_t& o = out[i];
+    memset(&o, 0, sizeof o);
+    o.link = links[i].index;
+    o.state = links[i].state;
+    o.peer_gpu = -1;
+    for (size_t p = 0; p < s.st.size(); p++)
+      if (p != gpu && !links[i].peer_bdf.empty() && s.st[p].pci_bdf == links[i].peer_bdf) o.peer_gpu = (int32_t)p;
+    copy_str(o.peer_bdf, links[i].peer_bdf);
+    o.bit_rate_gbps = links[i].bit_rate_gbps;
+    o.max_bandwidth_gbps = links[i].max_bandwidth_gbps;
+    o.rx_kb = links[i].rx_kb;
+    o.tx_kb = links[i].tx_kb;
+  }
+  return GM_ST_OK;
+}
+
 gm_status_t gm_smi_peer_link(uint32_t gpu, uint32_t peer, gm_peer_link_t* out) {
   Smi& s = S();
   SMI_READY(s);

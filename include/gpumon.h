@@ -222,6 +222,7 @@ enum {
   GM_FI_XGMI_LINK_SPEED = 479, /* Gbps per lane */
   GM_FI_XGMI_LINKS_UP = 480,
   GM_FI_XGMI_LINKS_DOWN = 481,
+  GM_FI_XGMI_ERROR_STATUS = 482, /* 0 no errors, 1 an error, 2 several errors latched by the link layer */
 
   /* profiling-class metrics (`-p`), % */
   GM_FI_PROF_GR_ENGINE_ACTIVE = 1001,
@@ -383,6 +384,22 @@ typedef struct {
 #define GM_TOPOLOGY_VERSION GM_VERSION(gm_topology_t, 1)
 
 GM_API gm_status_t gm_device_topology(uint32_t gpu, gm_topology_t* out);
+
+/* One physical xGMI link of a GPU: its state, who sits at the other end, its rate and its traffic counters —
+ * what the reference gets by walking nvmlDeviceGetNvLinkState / RemotePciInfo over the link indices
+ * (bindings/go/nvml/bindings.go:268-318).  `link` is the index the per-link telemetry fields use
+ * (GM_FI_XGMI_LINK_*_0 + link). */
+typedef struct {
+  uint32_t link;
+  int32_t state;             /* 1 up, 0 down, -1 not wired / not reported */
+  int32_t peer_gpu;          /* engine index of the GPU at the other end; -1 when it is not one of ours or unknown */
+  char peer_bdf[GM_STR_LEN]; /* PCI address of the other end; empty when the platform does not say */
+  int64_t bit_rate_gbps;     /* current rate; -1 = blank */
+  int64_t max_bandwidth_gbps;
+  int64_t rx_kb, tx_kb;      /* cumulative; -1 = blank */
+} gm_xgmi_link_t;
+/* *n in = capacity of out (GM_MAX_XGMI_LINKS is enough), out = links reported. */
+GM_API gm_status_t gm_xgmi_links(uint32_t gpu, gm_xgmi_link_t* out, int* n);
 GM_API const char* gm_link_type_name(int32_t link, uint32_t hops);  /* "XGMI1", "PIX", ... */
 GM_API const char* gm_link_type_description(int32_t link);
 
@@ -521,6 +538,39 @@ GM_API gm_status_t gm_health_set(gm_group_t g, uint32_t systems);
 GM_API gm_status_t gm_health_get(gm_group_t g, uint32_t* systems);
 /* One response per GPU of the group; *n in = capacity, out = count. */
 GM_API gm_status_t gm_health_check(gm_group_t g, gm_health_response_t* out, int* n);
+
+/* Levels the health checks compare against.  Defaults suit MI355X-class parts; every daemon takes them as flags
+ * (--health-hotspot-warn ...), from its config file and from $GPUMON_ARGS. */
+typedef struct {
+  uint32_t version;
+  int32_t hotspot_warn_c, hotspot_fail_c; /* 100 / 110 */
+  int32_t mem_warn_c, mem_fail_c;         /* 95 / 105 */
+  int32_t bad_pages_fail;                 /* 256: the RAS bad-page table is nearly full */
+  int32_t ce_burst_warn;                  /* 100 correctable errors between two checks */
+  double power_over_cap_warn;             /* 1.10: socket power above cap x this */
+} gm_health_thresholds_t;
+#define GM_HEALTH_THRESHOLDS_VERSION GM_VERSION(gm_health_thresholds_t, 1)
+GM_API gm_status_t gm_health_thresholds_set(const gm_health_thresholds_t* t);
+GM_API gm_status_t gm_health_thresholds_get(gm_health_thresholds_t* t);
+
+/* Result of an active diagnostic (gpumon-diag: memtest, HBM stream, MFMA / GEMM stress, link tests) handed to the
+ * engine.  A failed or degraded result stays with the GPU until a later result of the same test replaces it: health
+ * checks report it under `system`, and a FAIL also raises a GM_EVENT_DIAG_FAIL event (GPU-event policy,
+ * GM_FI_LAST_EVENT_CODE). */
+typedef struct {
+  uint32_t version;
+  uint32_t gpu;
+  char test[32];    /* "memtest", "hbm_stream", "gemm_bf16", "xgmi_p2p", ... */
+  uint32_t system;  /* one GM_HEALTH_WATCH_* bit the result belongs to */
+  int32_t health;   /* gm_health_result_t */
+  double value;     /* the number the verdict rests on (errors, TB/s, TFLOP/s, GB/s); NaN when there is none */
+  int64_t ts_us;    /* when the test finished; 0 = now */
+  char message[192];
+} gm_diag_result_t;
+#define GM_DIAG_RESULT_VERSION GM_VERSION(gm_diag_result_t, 1)
+GM_API gm_status_t gm_diag_result_submit(const gm_diag_result_t* r);
+/* Latest result per (GPU, test); *n in = capacity, out = count. */
+GM_API gm_status_t gm_diag_results(uint32_t gpu, gm_diag_result_t* out, int* n);
 GM_API const char* gm_health_system_name(uint32_t system);
 GM_API const char* gm_health_result_name(int32_t health);
 
@@ -572,6 +622,7 @@ enum {
   GM_EVENT_RAS_UE = 5,
   GM_EVENT_RAS_POISON = 6,
   GM_EVENT_RING_HANG = 7,
+  GM_EVENT_DIAG_FAIL = 8, /* an active diagnostic failed on this GPU (gm_diag_result_submit) */
   GM_EVENT_PROCESS_START = 20, /* not critical: never a violation */
   GM_EVENT_PROCESS_END = 21
 };
@@ -763,6 +814,7 @@ GM_API gm_status_t gm_smi_device_status(uint32_t gpu, gm_device_status_t* out);
 GM_API gm_status_t gm_smi_read_fields(uint32_t gpu, const uint16_t* field_ids, int n, gm_value_t* out);
 GM_API gm_status_t gm_smi_device_processes(uint32_t gpu, gm_process_t* out, int* n);
 GM_API gm_status_t gm_smi_peer_link(uint32_t gpu, uint32_t peer, gm_peer_link_t* out);
+GM_API gm_status_t gm_smi_xgmi_links(uint32_t gpu, gm_xgmi_link_t* out, int* n);
 GM_API gm_status_t gm_smi_device_mode(uint32_t gpu, gm_device_mode_t* out);
 /* Blocks up to timeout_ms for the next driver event (reset, RAS, thermal...);
  * GM_ST_TIMEOUT when none arrived, GM_ST_NOT_SUPPORTED when the platform has no event channel. */

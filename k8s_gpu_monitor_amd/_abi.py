@@ -54,14 +54,16 @@ FI = dict(
     LAST_EVENT_CODE=230, POWER_VIOLATION=240, THERMAL_VIOLATION=241, VRAM_TOTAL=250, VRAM_FREE=251,
     VRAM_USED=252, ECC_CE_VOLATILE=310, ECC_UE_VOLATILE=311, ECC_UMC_UE=321, BAD_PAGES_CE=390,
     BAD_PAGES_UE=391, BAD_PAGES_PENDING=392, XGMI_CRC_ERRORS=409, XGMI_DATA_ERRORS=419,
-    XGMI_BANDWIDTH_TOTAL=449, XGMI_LINK_STATUS_0=470, XGMI_LINKS_DOWN=481, PROF_GR_ENGINE_ACTIVE=1001,
+    XGMI_BANDWIDTH_TOTAL=449, XGMI_LINK_STATUS_0=470, XGMI_LINKS_DOWN=481, XGMI_ERROR_STATUS=482,
+    PROF_GR_ENGINE_ACTIVE=1001, LOW_UTIL_VIOLATION=244, RELIABILITY_VIOLATION=245, THROTTLE_STATUS=246, ECC_DEFERRED=314,
 )
+THROTTLE = dict(POWER=1, THERMAL=2, HBM_THERMAL=4, VR_THERMAL=8, PROCHOT=16, LOW_UTIL=32, HOST_LIMIT=64)
 
 HEALTH = dict(PCIE=1, XGMI=2, MEM=4, COMPUTE=8, THERMAL=16, POWER=32, DRIVER=64, FIRMWARE=128, ALL=0xFF)
 HEALTH_PASS, HEALTH_WARN, HEALTH_FAIL = 0, 10, 20
 POLICY = dict(ECC_UE=1, PCIE=2, MAX_BAD_PAGES=4, THERMAL=8, POWER=16, XGMI=32, GPU_EVENT=64, ALL=0x7F)
 EVENT = dict(NONE=0, VMFAULT=1, THERMAL_THROTTLE=2, GPU_PRE_RESET=3, GPU_POST_RESET=4, RAS_UE=5,
-             RAS_POISON=6, RING_HANG=7, PROCESS_START=20, PROCESS_END=21)
+             RAS_POISON=6, RING_HANG=7, DIAG_FAIL=8, PROCESS_START=20, PROCESS_END=21)
 
 
 def _version(struct, n=1):
@@ -117,6 +119,22 @@ class PeerLink(C.Structure):
     _fields_ = [("gpu", C.c_uint32), ("link", C.c_int32), ("hops", C.c_uint32), ("num_links", C.c_uint32),
                 ("weight", C.c_uint64), ("min_bw_mbs", C.c_int64), ("max_bw_mbs", C.c_int64),
                 ("p2p_accessible", C.c_int32), ("pci_bdf", C.c_char * GM_STR_LEN)]
+
+
+class XgmiLink(C.Structure):
+    _fields_ = [("link", C.c_uint32), ("state", C.c_int32), ("peer_gpu", C.c_int32), ("peer_bdf", C.c_char * GM_STR_LEN),
+                ("bit_rate_gbps", C.c_int64), ("max_bandwidth_gbps", C.c_int64), ("rx_kb", C.c_int64), ("tx_kb", C.c_int64)]
+
+
+class HealthThresholds(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("hotspot_warn_c", C.c_int32), ("hotspot_fail_c", C.c_int32),
+                ("mem_warn_c", C.c_int32), ("mem_fail_c", C.c_int32), ("bad_pages_fail", C.c_int32),
+                ("ce_burst_warn", C.c_int32), ("power_over_cap_warn", C.c_double)]
+
+
+class DiagResult(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("gpu", C.c_uint32), ("test", C.c_char * 32), ("system", C.c_uint32),
+                ("health", C.c_int32), ("value", C.c_double), ("ts_us", C.c_int64), ("message", C.c_char * 192)]
 
 
 class Topology(C.Structure):

@@ -62,6 +62,11 @@ def lib():
         "gm_supported_devices": (st, [u32p, C.POINTER(C.c_int)]),
         "gm_device_attributes": (st, [C.c_uint32, C.POINTER(A.DeviceAttributes)]),
         "gm_device_topology": (st, [C.c_uint32, C.POINTER(A.Topology)]),
+        "gm_xgmi_links": (st, [C.c_uint32, C.POINTER(A.XgmiLink), C.POINTER(C.c_int)]),
+        "gm_health_thresholds_set": (st, [C.POINTER(A.HealthThresholds)]),
+        "gm_health_thresholds_get": (st, [C.POINTER(A.HealthThresholds)]),
+        "gm_diag_result_submit": (st, [C.POINTER(A.DiagResult)]),
+        "gm_diag_results": (st, [C.c_uint32, C.POINTER(A.DiagResult), C.POINTER(C.c_int)]),
         "gm_link_type_name": (C.c_char_p, [C.c_int32, C.c_uint32]),
         "gm_link_type_description": (C.c_char_p, [C.c_int32]),
         "gm_group_create": (st, [C.c_char_p, u32p]),

@@ -80,6 +80,23 @@ def device_topology(gpu):
     return {"gpu": t.gpu, "cpu_affinity": t.cpu_affinity.decode(), "numa_node": t.numa_node, "peers": peers}
 
 
+def xgmi_links(gpu):
+    """Every physical xGMI link of the GPU: state (1 up, 0 down, -1 unknown), the GPU and PCI address at the far
+    end, rate and traffic counters (None where the platform does not say)."""
+    buf = (A.XgmiLink * 64)()
+    n = C.c_int(64)
+    check(lib().gm_xgmi_links(gpu, buf, C.byref(n)), f"xgmi_links({gpu})")
+    out = []
+    for i in range(n.value):
+        d = _struct_dict(buf[i], skip=())
+        for k in ("bit_rate_gbps", "max_bandwidth_gbps", "rx_kb", "tx_kb"):
+            if d[k] < 0:
+                d[k] = None
+        d["peer_gpu"] = None if d["peer_gpu"] < 0 else d["peer_gpu"]
+        out.append(d)
+    return out
+
+
 def device_status(gpu):
     d = A.versioned(A.DeviceStatus)
     check(lib().gm_device_status(gpu, C.byref(d)), f"device_status({gpu})")
@@ -221,6 +238,38 @@ def health_check(group):
     return out
 
 
+def health_thresholds_get():
+    t = A.versioned(A.HealthThresholds)
+    check(lib().gm_health_thresholds_get(C.byref(t)), "health_thresholds_get")
+    return _struct_dict(t)
+
+
+def health_thresholds_set(**levels):
+    """Change some of the health-check levels (hotspot_warn_c, hotspot_fail_c, mem_warn_c, mem_fail_c, bad_pages_fail,
+    ce_burst_warn, power_over_cap_warn); the others keep their values."""
+    t = A.versioned(A.HealthThresholds)
+    check(lib().gm_health_thresholds_get(C.byref(t)), "health_thresholds_get")
+    for k, v in levels.items():
+        if k not in dict(A.HealthThresholds._fields_) or k == "version":
+            raise ValueError(f"unknown health threshold {k}")
+        setattr(t, k, v)
+    check(lib().gm_health_thresholds_set(C.byref(t)), "health_thresholds_set")
+
+
+def diag_result_submit(gpu, test, system, health, message="", value=float("nan"), ts_us=0):
+    """Hand the verdict of an active diagnostic to the engine (see gm_diag_result_t)."""
+    d = A.versioned(A.DiagResult)
+    d.gpu, d.test, d.system, d.health, d.value, d.ts_us, d.message = gpu, _b(test), system, health, value, ts_us, _b(message)
+    check(lib().gm_diag_result_submit(C.byref(d)), "diag_result_submit")
+
+
+def diag_results(gpu):
+    buf = (A.DiagResult * 64)()
+    n = C.c_int(64)
+    check(lib().gm_diag_results(gpu, buf, C.byref(n)), "diag_results")
+    return [_struct_dict(buf[i]) for i in range(n.value)]
+
+
 def health_check_gpu(gpu):
     """Same shape as the reference's HealthCheckByGpuId (bindings/go/dcgm/health.go:34-86)."""
     g = group_create(f"py-health-{gpu}-{id(object())}", [gpu])
@@ -343,6 +392,12 @@ class EventSet:
         if self.es:
             lib().gm_event_set_free(self.es)
             self.es = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 # ---- exporter ---------------------------------------------------------------------

@@ -32,6 +32,7 @@ def _L():
             "gm_smi_read_fields": [C.c_uint32, C.POINTER(C.c_uint16), C.c_int, C.POINTER(A.Value)],
             "gm_smi_device_processes": [C.c_uint32, C.POINTER(A.Process), C.POINTER(C.c_int)],
             "gm_smi_peer_link": [C.c_uint32, C.c_uint32, C.POINTER(A.PeerLink)],
+            "gm_smi_xgmi_links": [C.c_uint32, C.POINTER(A.XgmiLink), C.POINTER(C.c_int)],
             "gm_smi_device_mode": [C.c_uint32, C.POINTER(A.DeviceMode)],
             "gm_smi_event_wait": [C.c_int32, C.POINTER(A.Event)], "gm_smi_fake_ctl": [C.c_char_p],
         }
@@ -132,6 +133,22 @@ def peer_link(gpu, peer):
     d = _struct_dict(p, skip=())
     d["link_name"] = lib().gm_link_type_name(p.link, p.hops).decode()
     return d
+
+
+def xgmi_links(gpu):
+    """Every physical xGMI link of the GPU, straight from the device library (same shape as engine.xgmi_links)."""
+    buf = (A.XgmiLink * 64)()
+    n = C.c_int(64)
+    check(_L().gm_smi_xgmi_links(gpu, buf, C.byref(n)), f"smi.xgmi_links({gpu})")
+    out = []
+    for i in range(n.value):
+        d = _struct_dict(buf[i], skip=())
+        for k in ("bit_rate_gbps", "max_bandwidth_gbps", "rx_kb", "tx_kb"):
+            if d[k] < 0:
+                d[k] = None
+        d["peer_gpu"] = None if d["peer_gpu"] < 0 else d["peer_gpu"]
+        out.append(d)
+    return out
 
 
 def device_topology(gpu):

@@ -252,8 +252,11 @@ def test_amd_extras_and_self_metrics(engine2):
         ex.sweep()
         fams = parse(ex.render())
     link = fams["gpumon_xgmi_link_rx_kb_total"]
-    assert [list(l.keys()) for l, _ in link.samples][0] == ["gpu", "uuid", "link"]
+    assert [list(l.keys()) for l, _ in link.samples][0] == ["gpu", "uuid", "link", "peer"]
     assert {l["link"] for l, _ in link.samples} == {"0"}  # a 2-GPU node wires one link per GPU
+    # the far end of every link is named: link 0 of GPU 0 goes to GPU 1 and back
+    assert {(l["gpu"], l["peer"]) for l, _ in link.samples} == {("0", "1"), ("1", "0")}
+    assert fams["gpumon_xgmi_error_status"].samples[0][1] == 0
     assert {l["stack"] for l, _ in fams["gpumon_hbm_stack_temp"].samples} == {str(i) for i in range(8)}
     assert {l["xcd"] for l, _ in fams["gpumon_xcd_busy"].samples} == {str(i) for i in range(8)}
     assert {l["block"] for l, _ in fams["gpumon_ecc_block_uncorrectable_total"].samples} == {

@@ -46,8 +46,10 @@ def test_health_incidents_by_subsystem(engine):
     E.fake_ctl("pcie_replay gpu=2 count=5")     # PCIe replays -> warning
     E.fake_ctl("set gpu=3 field=150 value=104")  # hot -> thermal warning
     r = _health(g)
-    assert r[0]["status"] == "Failure" and _types(r[0]) == [("Memory watches", "Failure")]
-    assert "2 uncorrectable HBM" in r[0]["watches"][0]["error"]
+    # the step of the uncorrectable total is also a RAS event (the XID analog): memory AND driver watch fail
+    assert r[0]["status"] == "Failure" and _types(r[0]) == [("Driver / RAS event watches", "Failure"), ("Memory watches", "Failure")]
+    assert "2 uncorrectable HBM" in " ".join(w["error"] for w in r[0]["watches"])
+    assert "RAS uncorrectable error" in " ".join(w["error"] for w in r[0]["watches"])
     assert r[1]["status"] == "Failure" and ("xGMI watches", "Failure") in _types(r[1])
     assert "link 3 is down" in " ".join(w["error"] for w in r[1]["watches"])
     assert r[2]["status"] == "Warning" and _types(r[2]) == [("PCIe watches", "Warning")]
@@ -74,7 +76,7 @@ def test_health_more_subsystems(engine):
     E.fake_ctl("ecc gpu=4 block=4 ce=7")            # xGMI correctable -> warning
     time.sleep(0.3)  # the event travels through the event thread
     r = _health(g)
-    assert _types(r[0]) == [("Compute (XCD) watches", "Failure")]
+    assert _types(r[0]) == [("Compute (XCD) watches", "Failure"), ("Driver / RAS event watches", "Failure")]
     assert _types(r[1]) == [("Memory watches", "Warning")] and "pending retirement" in r[1]["watches"][0]["error"]
     assert _types(r[2]) == [("Power watches", "Warning"), ("Thermal watches", "Warning")]
     assert _types(r[3]) == [("Driver / RAS event watches", "Failure")]
@@ -148,17 +150,23 @@ def test_every_condition_delivers_its_payload(engine):
         E.fake_ctl("event gpu=3 code=1 msg=vmfault")
         E.update_all_fields(True)
         deadline = time.time() + 5
-        while len(got) < 7 and time.time() < deadline:
+        events = []
+        while (len(got) < 7 or len(events) < 2) and time.time() < deadline:
             v = reg.wait(500)
             if v:
                 got[v["condition"]] = v
+                if v["condition"] == P["GPU_EVENT"]:
+                    events.append(v["data"])
     assert set(got) == {P["ECC_UE"], P["PCIE"], P["MAX_BAD_PAGES"], P["THERMAL"], P["POWER"], P["XGMI"], P["GPU_EVENT"]}
     assert got[P["ECC_UE"]]["data"] == {"location": "HBM (UMC)", "count": 1}
     assert got[P["PCIE"]]["data"] == {"replay_counter": 2}
     assert got[P["MAX_BAD_PAGES"]]["data"] == {"ce_pages": 0, "ue_pages": 5}
     assert got[P["POWER"]]["data"]["power_w"] >= 900
     assert got[P["XGMI"]]["data"]["link"] == 2
-    assert got[P["GPU_EVENT"]]["data"] == {"code": 1, "message": "vmfault"}
+    # two GPU events: the injected VM fault, and the RAS event the engine derives from the uncorrectable-error step
+    assert sorted(e["code"] for e in events) == [1, 5]
+    assert {"code": 1, "message": "vmfault"} in events
+    assert [e["message"] for e in events if e["code"] == 5] == ["RAS: 1 uncorrectable error(s) since the last sample (total 1)"]
 
 
 def test_policy_callback_thread_and_unregister(engine):
