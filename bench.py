@@ -48,6 +48,9 @@ class Sizes:
         self.coll_bytes = (1 << 20) if dry else (1 << 30)
 
 
+EXPORTER_WINDOW_S = 10.0  # shortest window the exporter's CPU share is measured over
+
+
 class ExporterChild:
     """gpumon-exporter as a child process (started before this process touches the GPU)."""
 
@@ -289,8 +292,29 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     try:
+        # The communicator must span exactly N ranks on N different devices: a launcher that put two ranks on one GPU,
+        # or a communicator that came up smaller, would still produce numbers.
+        ranks_seen, devices_seen = 1, 1
+        if world > 1:
+            if a.dry_run:
+                ident = f"cpu-rank{rank}"
+            else:
+                props = torch.cuda.get_device_properties(dev)
+                ident = "/".join(str(getattr(props, k, "?")) for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"))
+            seen = [None] * world
+            dist.all_gather_object(seen, (rank, ident))
+            ranks_seen, devices_seen = len({r for r, _ in seen}), len({d for _, d in seen})
+            if dist.get_world_size() != world or ranks_seen != world:
+                sys.exit(f"bench: asked for {world} ranks, the communicator has {dist.get_world_size()} ({ranks_seen} distinct)")
+            if devices_seen != world and rank == 0:
+                # Recorded rather than fatal: the identity comes from the runtime's device properties, and a runtime that
+                # reports the same identity for every card must not stop a correct job.
+                print(f"bench: {world} ranks report {devices_seen} distinct device identities: {sorted(d for _, d in seen)}",
+                      file=sys.stderr)
         kernels = (DryKernels if a.dry_run else GpuKernels)(torch, dev, sz, a.gemm_launches, rank)
         result = run(a, world, dev, exporter, torch, dist, kernels, sz, busbw_factor)
+        result["extras"]["collective_ranks"] = ranks_seen
+        result["extras"]["collective_devices"] = devices_seen
         if exporter_error:
             result["extras"]["exporter_error"] = exporter_error
     finally:
@@ -358,16 +382,29 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
             dist.barrier()
         K.sync()
 
+    # Exporter cost is a ratio of two small numbers at a 1 s sampling period: it is measured over a window of its own
+    # that starts here and lasts at least EXPORTER_WINDOW_S, however short the timed region is.
+    cpu_w0, t_w0 = (exporter.cpu_seconds(), time.perf_counter()) if exporter else (0.0, 0.0)
     for i in range(a.warmup):
         step(i)
     fence()
-    cpu0 = exporter.cpu_seconds() if exporter else 0.0
     t0 = time.perf_counter()
     for i in range(a.warmup, total_steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    cpu1 = exporter.cpu_seconds() if exporter else 0.0
+    exporter_window_s, exporter_cpu_s = 0.0, 0.0
+    if exporter:  # outside the timed region: keep scraping once a second until the window is long enough
+        while time.perf_counter() - t_w0 < EXPORTER_WINDOW_S:
+            time.sleep(min(1.0, max(0.0, EXPORTER_WINDOW_S - (time.perf_counter() - t_w0))))
+            try:
+                exporter.scrape()
+            except OSError:
+                break
+        exporter_window_s = time.perf_counter() - t_w0
+        exporter_cpu_s = exporter.cpu_seconds() - cpu_w0
+    if world > 1:
+        dist.barrier()  # the other ranks wait for rank 0's window before anything is torn down
 
     # ---- reduce over ranks ----
     ph_ms = torch.zeros(len(phases), dtype=torch.float64)
@@ -418,7 +455,8 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
             "scrape_p99_ms": round(q[98], 3),
             "scrape_bytes": scrape_bytes,
             "scrapes": len(scrape_ms),
-            "exporter_cpu_percent_of_one_core": round(100.0 * (cpu1 - cpu0) / elapsed, 2),
+            "exporter_cpu_percent_of_one_core": round(100.0 * exporter_cpu_s / max(exporter_window_s, 1e-9), 3),
+            "exporter_cpu_window_s": round(exporter_window_s, 2),
             "exporter_rss_kb": exporter.rss_kb(),
             "exporter_interval_ms": 1000,
             "exporter_prof_counters": bool(a.prof_counters),

@@ -172,6 +172,7 @@ class Backend {
 
 std::unique_ptr<Backend> make_fake_backend(const std::string& spec);
 std::unique_ptr<Backend> make_amdsmi_backend(const std::string& library_path);
+std::unique_ptr<Backend> make_replicate_backend(std::unique_ptr<Backend> inner, uint32_t times);
 // "amdsmi" | "fake"; nullptr on an unknown name.
 std::unique_ptr<Backend> make_backend(const std::string& name, const std::string& spec);
 

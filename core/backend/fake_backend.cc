@@ -517,10 +517,22 @@ std::unique_ptr<Backend> make_fake_backend(const std::string& spec) {
   return std::unique_ptr<Backend>(new FakeBackend(spec));
 }
 
+// "replicate=N" anywhere in a comma-separated spec wraps the backend so that every GPU appears N times
+// (replicate_backend.cc).  For amdsmi the rest of the spec is "lib=PATH" or a bare library path.
 std::unique_ptr<Backend> make_backend(const std::string& name, const std::string& spec) {
-  if (name == "fake") return make_fake_backend(spec);
-  if (name == "amdsmi" || name.empty()) return make_amdsmi_backend(spec);
-  return nullptr;
+  uint32_t replicate = 0;
+  std::string rest, lib;
+  for (auto& kv : split(spec, ',')) {
+    const std::string t = trim(kv);
+    if (t.compare(0, 10, "replicate=") == 0) replicate = (uint32_t)std::max(0, atoi(t.c_str() + 10));
+    else if (t.compare(0, 4, "lib=") == 0) lib = t.substr(4);
+    else if (!t.empty()) rest += (rest.empty() ? "" : ",") + t;
+  }
+  std::unique_ptr<Backend> b;
+  if (name == "fake") b = make_fake_backend(rest);
+  else if (name == "amdsmi" || name.empty()) b = make_amdsmi_backend(!lib.empty() ? lib : rest);
+  if (b && replicate > 1) b = make_replicate_backend(std::move(b), replicate);
+  return b;
 }
 
 }  // namespace gpumon
