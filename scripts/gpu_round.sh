@@ -34,10 +34,19 @@ for s in $STEPS; do
       step diag_run2 600 build/bin/gpumon-diag run -r 2
       step diag_rccl 300 build/bin/gpumon-diag rccl --max-bytes 256M --factor 16
       ;;
-    gemmcheck) step gemm_check 600 python -u scripts/gpu_gemm_check.py ;;
     scrape)
       # exporter cost at 1 s resolution: real device library, then the same binary while the GPU soaks
       step scrape_amdsmi 120 python -u scripts/scrape_bench.py --backend amdsmi --seconds 30 --out "$OUT/scrape_amdsmi.json"
+      ;;
+    scrape8)
+      # an 8-GPU node's sampling cost on the real library: every device presented eight times, 1 s and 100 ms resolution
+      step scrape_amdsmi_x8 150 python -u scripts/scrape_bench.py --backend amdsmi --replicate 8 --seconds 62 --out "$OUT/scrape_amdsmi_x8.json"
+      step scrape_amdsmi_x8_100ms 150 python -u scripts/scrape_bench.py --backend amdsmi --replicate 8 --seconds 62 --interval-ms 100 --out "$OUT/scrape_amdsmi_x8_100ms.json"
+      ;;
+    vendorclock)
+      export TMPDIR=/tmp
+      step vendor_clock 400 timeout -s KILL 380 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$PWD/$OUT/vendor_clock" -o v -- python3 scripts/gpu_gemm_vendor_clock.py
+      step vendor_clock_summary 60 python scripts/vendor_clock_summary.py "$OUT/vendor_clock" "$OUT/gemm_vendor_clock.md"
       ;;
     probe) step probe 300 python -u scripts/gpu_probe.py ;;
     copyref) step copy_ref 300 python -u scripts/gpu_copy_ref.py ;;
@@ -45,6 +54,7 @@ for s in $STEPS; do
       # kernel trace of a short bench run; rocprofv3 wants a writable cwd-independent TMPDIR
       export TMPDIR=/tmp
       step prof_bench 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$PWD/$OUT/prof_bench" -o bench -- python3 bench.py --steps 5 --warmup 2 --no-exporter
+      python scripts/prof_summary.py "$OUT/prof_bench" "$OUT/bench_kernel_trace.md" "bench.py --steps 5 --warmup 2: kernel trace" > /dev/null
       ;;
     pmc)
       # One counter pass per run (rocprofv3 does not multiplex): SQ pass, L2 read pass, L2 write/hit pass.

@@ -2,6 +2,11 @@
 """Condenses rocprofv3 CSV output (kernel trace and/or counter collection) into a
 small markdown report: per-kernel call counts and times, per-kernel counter sums.
 
+The register and LDS table comes from the code objects of the in-tree libraries
+(scripts/kernel_resources.py) where the kernel is one of ours: rocprofv3's own
+columns show 0 bytes of LDS for LDS requested at launch and no accumulator
+registers.  Kernels of other libraries keep rocprofv3's figures, marked as such.
+
 usage: prof_summary.py <dir-with-csv> <out.md> [title]
 """
 import csv
@@ -19,8 +24,21 @@ def short(name, n=72):
     return name if len(name) <= n else name[: n - 3] + "..."
 
 
+def code_object_table():
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import kernel_resources
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        libs = [os.path.join(root, "build", n) for n in ("libgpumon_diag.so", "libgpumon_prof.so")]
+        return kernel_resources.load([p for p in libs if os.path.exists(p)])
+    except Exception as e:  # the summary is still useful without the table
+        print(f"prof_summary: no code-object table ({e})", file=sys.stderr)
+        return {}
+
+
 def main():
     src, out = sys.argv[1], sys.argv[2]
+    ours = code_object_table()
     title = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(src.rstrip("/"))
     lines = [f"# {title}", ""]
     for path in sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)):
@@ -56,10 +74,16 @@ def main():
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].values()))[:20]:
             n = max(1, len(calls[k]))
             lines.append(f"| `{k}` | {n} | " + " | ".join(f"{v.get(c, 0) / n:.4g}" for c in counters) + " |")
-        lines += ["", "(counter values are per-dispatch means)", "", "| kernel | VGPR | AGPR | SGPR | LDS bytes | workgroup | grid |",
-                  "|---|---:|---:|---:|---:|---:|---:|"]
+        lines += ["", "(counter values are per-dispatch means)", "",
+                  "| kernel | VGPR (all) | of which AGPR | SGPR | VGPR spills | LDS bytes (static + at launch) | workgroup | grid | source |",
+                  "|---|---:|---:|---:|---:|---:|---:|---:|---|"]
         for k, r in regs.items():
-            lines.append(f"| `{k}` | " + " | ".join(r) + " |")
+            co = ours.get(k.split("(")[0])
+            if co:
+                lines.append(f"| `{k}` | {co['vgpr']} | {co['agpr']} | {co['sgpr']} | {co['spill_vgpr']} | "
+                             f"{co['lds_static']} + {co['lds_dynamic']} | {r[4]} | {r[5]} | code object |")
+            else:
+                lines.append(f"| `{k}` | {r[0]} | {r[1]} | {r[2]} | ? | {r[3]} | {r[4]} | {r[5]} | rocprofv3 |")
         lines.append("")
     with open(out, "w") as f:
         f.write("\n".join(lines) + "\n")

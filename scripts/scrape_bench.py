@@ -15,6 +15,10 @@ are the host engine's 0.08-0.165 % CPU and 11-18 MB RSS in sample outputs
 
   python scripts/scrape_bench.py --backend fake --gpus 8 --seconds 60
   python scripts/scrape_bench.py --backend amdsmi --seconds 30 --out gpurun_out/scrape_amdsmi.json
+  python scripts/scrape_bench.py --backend amdsmi --replicate 8 --seconds 60 --interval-ms 100
+
+--replicate N presents every real device N times (each read goes to the real
+library once per replica), which prices an N-GPU node's sampling on a one-GPU box.
 """
 import argparse
 import json
@@ -38,14 +42,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=8, help="fake backend only")
     ap.add_argument("--seconds", type=float, default=30)
     ap.add_argument("--scrape-hz", type=float, default=1.0)
+    ap.add_argument("--replicate", type=int, default=0, help="present every device of the backend N times")
+    ap.add_argument("--interval-ms", type=int, default=1000, help="exporter sampling interval (its floor is 100)")
     ap.add_argument("--out")
     a = ap.parse_args()
 
     from bench import ExporterChild
     from k8s_gpu_monitor_amd.utils.promparse import parse
-    if a.backend == "fake":
-        os.environ["GPUMON_BACKEND_SPEC"] = f"gpus={a.gpus},seed=1"
-    ex = ExporterChild(a.backend)
+    spec = [f"gpus={a.gpus}", "seed=1"] if a.backend == "fake" else []
+    if a.replicate > 1:
+        spec.append(f"replicate={a.replicate}")
+    if spec:
+        os.environ["GPUMON_BACKEND_SPEC"] = ",".join(spec)
+    ex = ExporterChild(a.backend, interval_ms=a.interval_ms)
     try:
         time.sleep(1.5)  # first sweep done, static attributes cached
         ex.scrape()
@@ -65,7 +74,7 @@ def main():
         gpus = len({l.get("gpu") for l, _ in fams["dcgm_sm_clock"].samples})
         self_metrics = {n: f.samples[0][1] for n, f in fams.items() if n.startswith("gpumon_") and len(f.samples) == 1}
         res = {
-            "backend": a.backend, "gpus": gpus, "sample_interval_ms": 1000, "scrape_hz": a.scrape_hz,
+            "backend": a.backend, "replicate": max(1, a.replicate), "gpus": gpus, "sample_interval_ms": a.interval_ms, "scrape_hz": a.scrape_hz,
             "seconds": round(wall, 1), "scrapes": len(lat),
             "scrape_ms": {"p50": round(statistics.median(lat), 3), "p90": round(pct(lat, 0.9), 3),
                           "p99": round(pct(lat, 0.99), 3), "max": round(max(lat), 3)},
