@@ -503,9 +503,9 @@ def test_pcie_throughput_and_xgmi_error_state_are_blank_where_the_library_has_no
     assert b[F["XGMI_ERROR_STATUS"]] in (None, 0, 1, 2)
     if cli.available():
         m = _amd_smi_dump("metric", "amd_smi_metric.json")[gpu]
-        bw = [val for k, val in m.items() if k.startswith("pcie.") and "bandwidth" in k]
-        if bw and all(x is None for x in bw):
-            assert b[F["PCIE_TX_KB"]] is None, (bw, b)
+        bw = [val for k, val in m.items() if k.startswith("pcie.current_bandwidth_")]  # sent / received, N/A on guests
+        assert len(bw) == 2, sorted(k for k in m if k.startswith("pcie."))
+        assert (b[F["PCIE_TX_KB"]] is None) == all(x is None for x in bw), (bw, b)
 
 
 def test_residency_durations_never_run_faster_than_the_wall_clock(hw):
