@@ -8,7 +8,7 @@
 //   gpumon-diag mfma   [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]
 //   gpumon-diag gemm   [-g GPU] [--dtype bf16|fp8|mxfp8] [--m M --n N --k K] [--seconds S] [--no-telemetry] [--mfma-counters]
 //   gpumon-diag rccl   [--gpus 0,1,..] [--ops a,b] [--min-bytes N] [--max-bytes N] [--scaling]
-//   gpumon-diag p2p    [--gpus 0,1,..] [--bytes N]
+//   gpumon-diag links  [--gpus 0,1,..] [--bytes N] [--modes uni,bidi,all] [--floor-gbps X]   (alias: p2p)
 //   gpumon-diag run -r 1|2|3 [-g GPU]      graded suites: quick / medium / long
 // Every command takes --json and --publish FILE (leave the JSON report where
 // `gpumon-exporter --diag-results` picks it up and exports it as gpumon_diag_* metrics).
@@ -20,6 +20,7 @@
 
 #include <strings.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdarg>
@@ -57,7 +58,8 @@ struct Args {
 
 const char* kFlagsWithValue[] = {"-g", "--bytes", "--iters", "--kernel", "--min-tbps", "--fraction", "--patterns", "--passes",
                                  "--dtype", "--seconds", "--m", "--n", "--k", "--gpus", "--ops", "--min-bytes",
-                                 "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor", "--publish"};
+                                 "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor", "--publish", "--modes", "--floor-gbps",
+                                 "--warn-ratio", "--fail-ratio", "--workgroups"};
 
 bool parse(const std::vector<std::string>& in, Args* a) {
   for (size_t i = 0; i < in.size(); i++) {
@@ -127,8 +129,21 @@ struct Report {
     int health;       // GM_HEALTH_PASS / WARN / FAIL
     double value;
     std::string message;
+    int gpu = -1;  // HIP device the verdict is about; -1 = the report's GPU
   };
   std::vector<Verdict> verdicts;
+  // A verdict about one GPU of a multi-GPU test (the link test): one per (test, gpu), the worst health wins.
+  void verdict_for_gpu(int gpu, const std::string& test, uint32_t system, int health, double value, const std::string& message) {
+    if (health == GM_HEALTH_FAIL) fail("GPU %d: %s", gpu, message.c_str());
+    for (auto& v : verdicts)
+      if (v.test == test && v.gpu == gpu) {
+        if (health > v.health) v.health = health, v.value = value, v.message = message;
+        return;
+      }
+    Verdict v{test, system, health, value, message};
+    v.gpu = gpu;
+    verdicts.push_back(v);
+  }
   void verdict_fail(const std::string& test, uint32_t system, double value, const char* fmt, ...) __attribute__((format(printf, 5, 6))) {
     char buf[192];
     va_list ap;
@@ -159,7 +174,8 @@ struct Report {
         if (c == '"' || c == '\\') msg += '\\';
         msg += (unsigned char)c < 0x20 ? ' ' : c;
       }
-      vj += std::string(i ? "," : "") + "{\"test\":\"" + v.test + "\",\"system\":" + std::to_string(v.system) + ",\"health\":" +
+      vj += std::string(i ? "," : "") + "{\"test\":\"" + v.test + "\"," + (v.gpu >= 0 ? "\"gpu\":" + std::to_string(v.gpu) + "," : "") +
+            "\"system\":" + std::to_string(v.system) + ",\"health\":" +
             std::to_string(v.health) + ",\"value\":" + num + ",\"message\":\"" + msg + "\"}";
     }
     return "{\"gpu\":" + std::to_string(gpu) + ",\"timestamp\":" + std::to_string((long long)time(nullptr)) +
@@ -642,7 +658,8 @@ int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, std::string
   int w = n ? pts[0].ndev : 0;
   r.text("# RCCL sweep on %d GPU%s\n# %-15s%14s%7s%12s%13s%13s  check\n", w, w == 1 ? "" : "s", "op", "bytes", "iters", "time(us)",
          "algbw(GB/s)", "busbw(GB/s)");
-  *js += "{\"gpus\":" + std::to_string(w) + ",\"points\":[";
+  // gmd_rccl_sweep fails unless every communicator reports exactly the requested rank count on its own device
+  *js += "{\"gpus\":" + std::to_string(w) + ",\"communicator_ranks\":" + std::to_string(w) + ",\"points\":[";
   for (int i = 0; i < n; i++) {
     auto& p = pts[i];
     r.text("  %-15s%14llu%7d%12.1f%13.2f%13.2f  %s\n", gmd_collective_name(p.op), (unsigned long long)p.bytes, p.iters, p.time_us,
@@ -703,32 +720,143 @@ int cmd_rccl(const Args& a, Report& r) {
   return 0;
 }
 
-int cmd_p2p(const Args& a, Report& r) {
+// Which physical link of a GPU leads to which peer, from the engine's link table (matched by PCI address, since
+// the compute runtime and the engine may number the cards differently).
+struct LinkMap {
+  bool on = false;
+  std::vector<int> engine_of;  // device-list position -> engine GPU index, -1 unknown
+  std::vector<std::vector<gm_xgmi_link_t>> links;  // per position
+  double per_direction_gbytes = 0;  // advertised rate of one direction of one link, GB/s; 0 unknown
+
+  void load(const std::vector<int>& hip_ids) {
+    gm_init_params_t p;
+    memset(&p, 0, sizeof p);
+    p.version = GM_INIT_PARAMS_VERSION;
+    p.mode = GM_MODE_EMBEDDED;
+    if (gm_init(&p) != GM_ST_OK) return;
+    on = true;
+    uint32_t n = 0;
+    gm_device_count(&n);
+    for (int hip : hip_ids) {
+      int idx = -1;
+      gmd_device_info_t d;
+      if (gmd_device_info(hip, &d) == GMD_OK)
+        for (uint32_t i = 0; i < n && idx < 0; i++) {
+          gm_device_attributes_t at;
+          memset(&at, 0, sizeof at);
+          at.version = GM_DEVICE_ATTRIBUTES_VERSION;
+          if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, d.pci_bdf) == 0) idx = (int)i;
+        }
+      engine_of.push_back(idx);
+      std::vector<gm_xgmi_link_t> l(64);
+      int cnt = (int)l.size();
+      if (idx < 0 || gm_xgmi_links((uint32_t)idx, l.data(), &cnt) != GM_ST_OK) cnt = 0;
+      l.resize(cnt);
+      for (auto& x : l)
+        if (x.max_bandwidth_gbps > 0) per_direction_gbytes = std::max(per_direction_gbytes, x.max_bandwidth_gbps / 8.0);
+      links.push_back(l);
+    }
+    gm_shutdown();
+  }
+  // Link index on position i whose far end is position j; -1 when the platform does not say.
+  int link_to(int i, int j) const {
+    if (!on || i >= (int)links.size() || j >= (int)engine_of.size() || engine_of[j] < 0) return -1;
+    for (auto& x : links[i])
+      if (x.peer_gpu == engine_of[j]) return (int)x.link;
+    return -1;
+  }
+};
+
+// xGMI link test: the peer-store matrix in three traffic patterns, graded per link.
+int cmd_links(const Args& a, Report& r) {
   std::vector<int> ids;
   if (!parse_gpus(a, &ids)) return 2;
-  int w = ids.empty() ? gmd_device_count() : (int)ids.size();
-  if (w <= 0) return 2;
-  std::vector<double> m((size_t)w * w);
-  DIAG_CALL(r, gmd_p2p_matrix(w, ids.empty() ? nullptr : ids.data(), a.size("--bytes", 256ull << 20), (int)a.num("--iters", 5), m.data()));
-  r.text("# peer copy bandwidth, GB/s (row = source GPU)\n");
-  std::string js = "[";
-  double lo = 1e300, hi = 0;
-  for (int i = 0; i < w; i++) {
-    js += std::string(i ? "," : "") + "[";
-    r.text("  ");
-    for (int j = 0; j < w; j++) {
-      double v = m[(size_t)i * w + j];
-      r.text("%8.1f", v);
-      js += std::string(j ? "," : "") + jnum(v);
-      if (i != j && v >= 0) lo = std::min(lo, v), hi = std::max(hi, v);
-      if (i != j && v < 0) r.fail("GPU %d cannot access GPU %d as a peer", i, j);
-    }
-    r.text("\n");
-    js += "]";
+  if (ids.empty())
+    for (int i = 0; i < gmd_device_count(); i++) ids.push_back(i);
+  const int w = (int)ids.size();
+  if (w <= 0) {
+    fprintf(stderr, "error: no GPU visible\n");
+    return 2;
   }
-  r.member("p2p_gbps", js + "]");
-  // One link well below its siblings is the signature of a degraded xGMI lane.
-  if (w > 1 && hi > 0 && lo < 0.6 * hi) r.fail("slowest pair %.1f GB/s is under 60 %% of the fastest (%.1f GB/s)", lo, hi);
+  if (w == 1) {
+    r.text("# xGMI link test: one GPU visible, no link to test\n");
+    r.member("links", "{\"gpus\":1,\"tested\":0}");
+    r.member("p2p_gbps", "[[0]]");
+    return 0;
+  }
+  LinkMap map;
+  map.load(ids);
+  // Absolute floor for one direction of one link: half the advertised rate unless given.  (The advertised rate is
+  // lanes x bit rate; protocol overhead and the store path keep a healthy link well above half of it.)
+  double floor = a.has("--floor-gbps") ? a.num("--floor-gbps", 0) : 0.5 * (map.per_direction_gbytes > 0 ? map.per_direction_gbytes : 76.0);
+  gmd_link_rule_t rule = {floor, a.num("--warn-ratio", 0), a.num("--fail-ratio", 0)};
+
+  gmd_link_config_t c;
+  memset(&c, 0, sizeof c);
+  c.ndev = w;
+  c.devices = ids.data();
+  c.bytes = a.size("--bytes", 256ull << 20);
+  c.iters = (int)a.num("--iters", 5);
+  c.verify = a.has("--no-verify") ? 0 : 1;
+  c.workgroups = (int)a.num("--workgroups", 0);
+
+  const char* names[] = {"uni", "bidi", "all"};
+  const char* what[] = {"one pair at a time", "both directions of a pair at once", "every GPU to every peer at once"};
+  std::vector<std::string> modes = a.has("--modes") ? csv(a.str("--modes")) : std::vector<std::string>{"uni", "bidi", "all"};
+  std::string js = "{\"gpus\":" + std::to_string(w) + ",\"floor_gbps\":" + jnum(floor);
+  std::vector<int> worst(w, GM_HEALTH_PASS);
+  std::vector<std::string> worst_msg(w);
+  std::vector<double> slowest(w, 1e300);
+  for (int mode = 0; mode < 3; mode++) {
+    if (std::find(modes.begin(), modes.end(), names[mode]) == modes.end()) continue;
+    std::vector<double> m((size_t)w * w);
+    std::vector<uint64_t> bad((size_t)w * w);
+    DIAG_CALL(r, gmd_link_test(&c, mode, m.data(), bad.data()));
+    r.text("# link bandwidth, GB/s, %s (row = source GPU)\n", what[mode]);
+    std::string mj = "[";
+    for (int i = 0; i < w; i++) {
+      mj += std::string(i ? "," : "") + "[";
+      r.text("  ");
+      for (int j = 0; j < w; j++) {
+        r.text("%8.1f", m[(size_t)i * w + j]);
+        mj += std::string(j ? "," : "") + jnum(m[(size_t)i * w + j]);
+      }
+      r.text("\n");
+      mj += "]";
+    }
+    js += std::string(",\"") + names[mode] + "\":" + mj + "]";
+    if (mode == GMD_LINK_UNI) r.member("p2p_gbps", mj + "]");
+    // The floor is one direction's; with both directions or all links busy a healthy link keeps most of it.
+    gmd_link_rule_t mr = rule;
+    mr.floor_gbps = mode == GMD_LINK_UNI ? floor : mode == GMD_LINK_BIDI ? 0.8 * floor : 0;
+    std::vector<gmd_link_verdict_t> v((size_t)w * (w - 1));
+    int nv = (int)v.size();
+    int rc = gmd_link_grade(w, m.data(), c.verify ? bad.data() : nullptr, &mr, v.data(), &nv);
+    if (rc < 0) return 2;
+    for (int k = 0; k < nv; k++) {
+      const int link = map.link_to(v[k].src, v[k].dst);
+      std::string where = "link " + (link >= 0 ? std::to_string(link) : std::string("?")) + " to GPU " + std::to_string(ids[v[k].dst]) +
+                          " (" + names[mode] + "): " + v[k].message;
+      if (v[k].health != GM_HEALTH_PASS) r.text("  %s GPU %d %s\n", v[k].health == GM_HEALTH_FAIL ? "FAIL" : "WARN", ids[v[k].src], where.c_str());
+      if (v[k].gbps >= 0) slowest[v[k].src] = std::min(slowest[v[k].src], v[k].gbps);
+      if (v[k].health > worst[v[k].src]) worst[v[k].src] = v[k].health, worst_msg[v[k].src] = where;
+    }
+  }
+  // link -> peer table, so that a verdict can be traced to a cable
+  std::string lj = "[";
+  bool any = false;
+  for (int i = 0; i < w; i++)
+    for (int j = 0; j < w; j++) {
+      const int link = i == j ? -1 : map.link_to(i, j);
+      if (link < 0) continue;
+      lj += std::string(any ? "," : "") + "{\"gpu\":" + std::to_string(ids[i]) + ",\"link\":" + std::to_string(link) + ",\"peer\":" + std::to_string(ids[j]) + "}";
+      any = true;
+    }
+  js += ",\"link_peers\":" + lj + "]}";
+  r.member("links", js);
+  for (int i = 0; i < w; i++)
+    r.verdict_for_gpu(ids[i], "xgmi_p2p", GM_HEALTH_WATCH_XGMI, worst[i], slowest[i] < 1e300 ? slowest[i] : std::nan(""),
+                      worst[i] == GM_HEALTH_PASS ? strprintf_local("%d links, slowest %.1f GB/s", w - 1, slowest[i]) : worst_msg[i]);
   return 0;
 }
 
@@ -761,21 +889,22 @@ int cmd_run(const Args& a, Report& r) {
     sub.kv.erase("--iters");
     sub.kv["--scaling"] = "1";
     if ((rc = cmd_rccl(sub, r))) return rc;
-    if (gmd_device_count() > 1 && (rc = cmd_p2p(sub, r))) return rc;
+    if (gmd_device_count() > 1 && (rc = cmd_links(sub, r))) return rc;
   }
   return 0;
 }
 
 void usage() {
   fprintf(stderr,
-          "usage: gpumon-diag <info|hbm|memtest|mfma|gemm|rccl|p2p|run> [options] [--json] [--publish FILE]\n"
+          "usage: gpumon-diag <info|hbm|memtest|mfma|gemm|rccl|links|run> [options] [--json] [--publish FILE]\n"
           "  --publish FILE leaves the JSON report where `gpumon-exporter --diag-results` picks it up\n"
           "  hbm     [-g GPU] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
           "  memtest [-g GPU] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N]\n"
           "  mfma    [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
           "  gemm    [-g GPU] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--min-tflops X] [--no-telemetry] [--mfma-counters]\n"
           "  rccl    [--gpus LIST] [--ops LIST] [--min-bytes N] [--max-bytes N] [--factor N] [--iters N] [--scaling] [--no-verify] [--min-busbw GBPS]\n"
-          "  p2p     [--gpus LIST] [--bytes N] [--iters N]\n"
+          "  links   [--gpus LIST] [--bytes N] [--iters N] [--modes uni,bidi,all] [--floor-gbps X] [--warn-ratio R] [--fail-ratio R]\n"
+          "          peer-store bandwidth of every xGMI link, graded against a floor and against the other links\n"
           "  run     -r 1|2|3 [-g GPU]\n"
           "every command: [--json] [--publish FILE] [--submit ENGINE_ADDRESS [--submit-unix]]\n");
 }
@@ -796,21 +925,26 @@ bool submit_verdicts(const Args& a, const Report& r) {
     fprintf(stderr, "error: cannot reach the host engine at %s: %s\n", addr.c_str(), gm_strerror(st));
     return false;
   }
-  uint32_t gpu = (uint32_t)a.num("-g", 0), n = 0;
-  gmd_device_info_t d;
-  if (gmd_device_info((int)gpu, &d) == GMD_OK && gm_device_count(&n) == GM_ST_OK)
-    for (uint32_t i = 0; i < n; i++) {
-      gm_device_attributes_t at;
-      memset(&at, 0, sizeof at);
-      at.version = GM_DEVICE_ATTRIBUTES_VERSION;
-      if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, d.pci_bdf) == 0) gpu = i;
-    }
+  // HIP device index -> the engine's index of the same card
+  auto engine_index = [](uint32_t hip) {
+    uint32_t n = 0;
+    gmd_device_info_t d;
+    if (gmd_device_info((int)hip, &d) == GMD_OK && gm_device_count(&n) == GM_ST_OK)
+      for (uint32_t i = 0; i < n; i++) {
+        gm_device_attributes_t at;
+        memset(&at, 0, sizeof at);
+        at.version = GM_DEVICE_ATTRIBUTES_VERSION;
+        if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, d.pci_bdf) == 0) return i;
+      }
+    return hip;
+  };
+  const uint32_t gpu = engine_index((uint32_t)a.num("-g", 0));
   bool ok = true;
   for (auto& v : r.verdicts) {
     gm_diag_result_t dr;
     memset(&dr, 0, sizeof dr);
     dr.version = GM_DIAG_RESULT_VERSION;
-    dr.gpu = gpu;
+    dr.gpu = v.gpu >= 0 ? engine_index((uint32_t)v.gpu) : gpu;
     snprintf(dr.test, sizeof dr.test, "%s", v.test.c_str());
     dr.system = v.system;
     dr.health = v.health;
@@ -848,7 +982,7 @@ int main(int argc, char** argv) {
   else if (cmd == "mfma") rc = cmd_mfma(a, r);
   else if (cmd == "gemm") rc = cmd_gemm(a, r);
   else if (cmd == "rccl") rc = cmd_rccl(a, r);
-  else if (cmd == "p2p") rc = cmd_p2p(a, r);
+  else if (cmd == "links" || cmd == "p2p") rc = cmd_links(a, r);
   else if (cmd == "run") rc = cmd_run(a, r);
   else {
     usage();

@@ -125,7 +125,8 @@ void submit_verdicts(const Json& r, Engine* engine) {
     gm_diag_result_t d;
     memset(&d, 0, sizeof d);
     d.version = GM_DIAG_RESULT_VERSION;
-    d.gpu = (uint32_t)num(r.get("gpu"), 0);
+    // a multi-GPU test (the link test) names the GPU in each verdict; the others are about the report's GPU
+    d.gpu = (uint32_t)num(v.get("gpu") ? v.get("gpu") : r.get("gpu"), 0);
     const Json* t = v.get("test");
     const Json* m = v.get("message");
     if (!t || t->type != Json::STR || t->str.empty()) continue;

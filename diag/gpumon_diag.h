@@ -220,6 +220,47 @@ GMD_API const char* gmd_collective_name(int op);
 GMD_API double gmd_busbw_factor(int op, int ndev);
 /* *n: capacity of out on entry, points written on return. */
 GMD_API int gmd_rccl_sweep(const gmd_rccl_config_t* cfg, gmd_rccl_point_t* out, int* n);
+
+/* Link test: a copy kernel on the source GPU stores straight into the peer's memory (16 bytes per lane,
+ * streaming stores), timed with HIP events on the source's stream, so the figure is the link's and not the
+ * copy engines'.  Three traffic patterns over the same buffers:
+ *   UNI   one ordered pair at a time              -> what one direction of one link carries
+ *   BIDI  both directions of a pair at once       -> whether the link holds its rate full duplex
+ *   ALL   every GPU writes to every peer at once  -> whether the links of a GPU are independent
+ * gbps[i*ndev+j] is the rate devices[i] -> devices[j] under that pattern (1e9 bytes/s), 0 on the diagonal,
+ * -1 without peer access.  With `verify`, bad[i*ndev+j] counts the 16-byte words that arrived different from
+ * what was sent (bad may be NULL).  One GPU: the 1x1 matrix {0}, GMD_OK. */
+typedef enum { GMD_LINK_UNI = 0, GMD_LINK_BIDI = 1, GMD_LINK_ALL = 2 } gmd_link_mode_t;
+typedef struct {
+  int32_t ndev;        /* 0 = all visible GPUs */
+  const int* devices;  /* NULL = 0..ndev-1 */
+  uint64_t bytes;      /* per transfer; default 256 MiB */
+  int32_t iters;       /* timed transfers per pair; default 5 */
+  int32_t verify;      /* 1 = check the data at the destination after the timed transfers */
+  int32_t workgroups;  /* copy kernel grid per peer; default 64 (256 lanes each) */
+} gmd_link_config_t;
+GMD_API int gmd_link_test(const gmd_link_config_t* cfg, int mode, double* gbps, uint64_t* bad);
+
+/* Grading of a link matrix, host arithmetic only (no GPU needed).  A pair fails when it has no peer access,
+ * delivered corrupt data, runs below the absolute floor, or below fail_ratio of the median of the other pairs;
+ * it warns below warn_ratio of that median.  The sibling median needs at least two other measured pairs;
+ * with fewer only the floor applies.  *n: capacity of out on entry, verdicts written on return (one per ordered
+ * pair, ndev*(ndev-1); none for one GPU).  Returns the worst health. */
+typedef struct {
+  double floor_gbps;  /* <= 0: no absolute floor */
+  double warn_ratio;  /* <= 0: 0.90 */
+  double fail_ratio;  /* <= 0: 0.75 */
+} gmd_link_rule_t;
+typedef struct {
+  int32_t src, dst;          /* positions in the device list */
+  int32_t health;            /* 0 pass, 10 warn, 20 fail (the engine's health scale) */
+  double gbps;
+  double sibling_median_gbps; /* 0 when there were not enough siblings */
+  char message[160];
+} gmd_link_verdict_t;
+GMD_API int gmd_link_grade(int ndev, const double* gbps, const uint64_t* bad, const gmd_link_rule_t* rule,
+                           gmd_link_verdict_t* out, int* n);
+
 /* Pairwise copy bandwidth over the GPU fabric with peer access (hipMemcpyPeerAsync):
  * gbps[i*ndev+j] = devices[i] -> devices[j], 0 on the diagonal, -1 where peer access
  * is not available.  On MI355X each ordered pair is one xGMI link. */

@@ -25,6 +25,9 @@ namespace {
   X(ncclGetErrorString)   \
   X(ncclCommInitAll)      \
   X(ncclCommDestroy)      \
+  X(ncclCommCount)        \
+  X(ncclCommUserRank)     \
+  X(ncclCommCuDevice)     \
   X(ncclGroupStart)       \
   X(ncclGroupEnd)         \
   X(ncclAllReduce)        \
@@ -265,6 +268,19 @@ int gmd_rccl_sweep(const gmd_rccl_config_t* cfg_in, gmd_rccl_point_t* out, int* 
   }
   s.comms.assign(w, nullptr);
   GMD_NCCL(R, R->ncclCommInitAll(s.comms.data(), w, ids.data()));
+  // The library's own view of what was built: w ranks, rank r on the r-th listed device.  A communicator that came
+  // up smaller, or with two ranks on one card, would still move data and produce plausible numbers.
+  for (int r = 0; r < w; r++) {
+    int count = 0, rank = -1, dev = -1;
+    GMD_NCCL(R, R->ncclCommCount(s.comms[r], &count));
+    GMD_NCCL(R, R->ncclCommUserRank(s.comms[r], &rank));
+    GMD_NCCL(R, R->ncclCommCuDevice(s.comms[r], &dev));
+    if (count != w || rank != r || dev != ids[r]) {
+      gmd::set_error("communicator %d reports %d ranks, rank %d on device %d; expected %d ranks, rank %d on device %d", r, count,
+                     rank, dev, w, r, ids[r]);
+      return GMD_ERR_VERIFY;
+    }
+  }
 
   std::vector<uint64_t> sizes;
   for (uint64_t b = cfg.min_bytes; b < cfg.max_bytes; b *= cfg.factor) sizes.push_back(b);

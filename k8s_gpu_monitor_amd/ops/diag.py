@@ -259,6 +259,59 @@ def p2p_matrix(devices=None, bytes=256 << 20, iters=5):
     return [[m[i * n + j] for j in range(n)] for i in range(n)]
 
 
+LINK_MODES = {"uni": 0, "bidi": 1, "all": 2}
+
+
+class LinkConfig(C.Structure):
+    _fields_ = [("ndev", C.c_int32), ("devices", C.POINTER(C.c_int)), ("bytes", C.c_uint64), ("iters", C.c_int32),
+                ("verify", C.c_int32), ("workgroups", C.c_int32)]
+
+
+class LinkRule(C.Structure):
+    _fields_ = [("floor_gbps", C.c_double), ("warn_ratio", C.c_double), ("fail_ratio", C.c_double)]
+
+
+class LinkVerdict(C.Structure):
+    _fields_ = [("src", C.c_int32), ("dst", C.c_int32), ("health", C.c_int32), ("gbps", C.c_double),
+                ("sibling_median_gbps", C.c_double), ("message", C.c_char * 160)]
+
+
+def link_test(mode="uni", devices=None, bytes=256 << 20, iters=5, verify=True, workgroups=0):
+    """Peer-store bandwidth matrix over the xGMI links (a copy kernel on the source GPU, HIP-event timed).
+    mode: "uni" one pair at a time, "bidi" both directions of a pair at once, "all" every GPU to every peer at
+    once.  Returns (gbps, bad): gbps[i][j] = devices[i] -> devices[j] in GB/s (-1 without peer access), bad[i][j] =
+    corrupt 16-byte words.  One GPU gives ([[0.0]], [[0]])."""
+    L = _lib()
+    L.gmd_link_test.argtypes = [C.POINTER(LinkConfig), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    n = len(devices) if devices else device_count()
+    arr = (C.c_int * n)(*devices) if devices else None
+    cfg = LinkConfig(n, arr, bytes, iters, 1 if verify else 0, workgroups)
+    m, b = (C.c_double * (n * n))(), (C.c_uint64 * (n * n))()
+    rc = L.gmd_link_test(C.byref(cfg), LINK_MODES[mode], m, b)
+    if rc:
+        raise DiagError(rc, f"gmd_link_test({mode})")
+    return [[m[i * n + j] for j in range(n)] for i in range(n)], [[b[i * n + j] for j in range(n)] for i in range(n)]
+
+
+def link_grade(gbps, bad=None, floor_gbps=0.0, warn_ratio=0.0, fail_ratio=0.0):
+    """Grades a link matrix (host arithmetic, no GPU): returns (worst_health, [verdict dict per ordered pair]).
+    Health is 0 pass / 10 warn / 20 fail; a pair fails without peer access, with corrupt data, under the absolute
+    floor or under fail_ratio (0.75) of the other pairs' median, and warns under warn_ratio (0.90) of it."""
+    L = _lib()
+    L.gmd_link_grade.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(LinkRule),
+                                 C.POINTER(LinkVerdict), C.POINTER(C.c_int)]
+    n = len(gbps)
+    m = (C.c_double * (n * n))(*[float(x) for row in gbps for x in row])
+    b = (C.c_uint64 * (n * n))(*[int(x) for row in bad for x in row]) if bad else None
+    rule = LinkRule(floor_gbps, warn_ratio, fail_ratio)
+    out = (LinkVerdict * max(1, n * (n - 1)))()
+    cnt = C.c_int(n * (n - 1))
+    rc = L.gmd_link_grade(n, m, b, C.byref(rule), out, C.byref(cnt))
+    if rc < 0:
+        raise DiagError(rc, "gmd_link_grade")
+    return rc, [_dict(out[i]) for i in range(cnt.value)]
+
+
 def gemm_launch(dtype, a_ptr, b_ptr, c_ptr, m, n, k, stream=None, scale_a=None, scale_b=None):
     """C[M,N] (bf16) = A[M,K] @ B[N,K]^T on caller memory.  dtype "mxfp8" takes the two packed E8M0 scale tensors
     (mx_pack_scales) as scale_a / scale_b device pointers; "fp8" is unscaled e4m3."""

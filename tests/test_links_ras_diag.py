@@ -226,3 +226,97 @@ def test_exporter_hands_report_verdicts_to_the_engine(engine, tmp_path):
     assert ("Compute (XCD) watches", "Failure") in [(w["type"], w["status"]) for w in r["watches"]]
     assert {d["test"] for d in E.diag_results(2)} == {"gemm_bf16", "hbm_stream"}
     assert E.latest_values(2, [F["LAST_EVENT_CODE"]])[F["LAST_EVENT_CODE"]] == A.EVENT["DIAG_FAIL"]
+
+
+def test_link_test_report_carries_one_verdict_per_gpu(engine, tmp_path):
+    """The link test is about several GPUs at once: its report names the GPU in every verdict, and the exporter hands
+    each to the engine under that GPU, not under the report's."""
+    rep = {"gpu": 0, "timestamp": 1_700_000_456, "result": "fail", "p2p_gbps": [[0, 64.0], [41.0, 0]],
+           "verdicts": [{"test": "xgmi_p2p", "gpu": 0, "system": H["XGMI"], "health": A.HEALTH_PASS, "value": 64.0,
+                         "message": "1 links, slowest 64.0 GB/s"},
+                        {"test": "xgmi_p2p", "gpu": 1, "system": H["XGMI"], "health": A.HEALTH_FAIL, "value": 41.0,
+                         "message": "link 0 to GPU 0 (uni): 41.0 GB/s is 64 % of the other links' median 64.0 GB/s"}]}
+    (tmp_path / "links.json").write_text(json.dumps(rep))
+    with E.Exporter(interval_ms=1000, diag_results_path=str(tmp_path)) as ex:
+        ex.sweep()
+        ex.render()
+    assert [(d["test"], d["health"]) for d in E.diag_results(0) if d["test"] == "xgmi_p2p"] == [("xgmi_p2p", A.HEALTH_PASS)]
+    got = [d for d in E.diag_results(1) if d["test"] == "xgmi_p2p"]
+    assert len(got) == 1 and got[0]["health"] == A.HEALTH_FAIL and "link 0 to GPU 0" in got[0]["message"]
+    g = E.group_create("lnkv", [0, 1])
+    E.health_set(g, H["XGMI"])
+    res = {r["gpu"]: r for r in E.health_check(g)}
+    assert res[1]["status"] == "Failure" and res[0]["status"] == "Healthy"
+
+
+# ------------------------------------------------------------ link grading --
+def _matrix(n, value, **cells):
+    m = [[0.0 if i == j else float(value) for j in range(n)] for i in range(n)]
+    for key, v in cells.items():
+        i, j = (int(x) for x in key[1:].split("_"))
+        m[i][j] = v
+    return m
+
+
+def test_link_grading_floor_and_sibling_ratio():
+    """The link test's verdict arithmetic (diag/hip/link_test.hip, gmd_link_grade) on synthetic matrices: an
+    8-GPU full mesh has 56 directed links; one slow lane fails against its siblings, a mildly slow one warns,
+    a uniformly slow fabric fails only because of the absolute floor."""
+    from k8s_gpu_monitor_amd.ops import diag
+    worst, v = diag.link_grade(_matrix(8, 64.0), floor_gbps=38.0)
+    assert worst == 0 and len(v) == 56 and all(x["health"] == 0 for x in v)
+    assert {(x["src"], x["dst"]) for x in v} == {(i, j) for i in range(8) for j in range(8) if i != j}
+    assert all(x["sibling_median_gbps"] == pytest.approx(64.0) for x in v)
+
+    worst, v = diag.link_grade(_matrix(8, 64.0, c0_4=40.0, c3_1=56.0), floor_gbps=38.0)
+    by = {(x["src"], x["dst"]): x for x in v}
+    assert worst == 20
+    assert by[(0, 4)]["health"] == 20 and "62 % of the other links' median 64.0" in by[(0, 4)]["message"]
+    assert by[(3, 1)]["health"] == 10 and "88 %" in by[(3, 1)]["message"]
+    assert sum(1 for x in v if x["health"]) == 2     # the slow lanes do not drag their siblings' median down
+    assert by[(4, 0)]["health"] == 0                 # the other direction of the same link is its own verdict
+
+    # every link equally slow: the ratio rule sees nothing, the floor does
+    worst, v = diag.link_grade(_matrix(8, 30.0), floor_gbps=38.0)
+    assert worst == 20 and all(x["health"] == 20 and "under the floor of 38.0" in x["message"] for x in v)
+    worst, v = diag.link_grade(_matrix(8, 30.0))
+    assert worst == 0
+
+    # thresholds are configurable; fail_ratio never exceeds warn_ratio
+    worst, v = diag.link_grade(_matrix(4, 60.0, c1_2=56.0), warn_ratio=0.99, fail_ratio=0.95)
+    assert worst == 20 and sum(1 for x in v if x["health"] == 20) == 1
+
+
+def test_link_grading_peer_access_corruption_and_small_hives():
+    from k8s_gpu_monitor_amd.ops import diag
+    m = _matrix(4, 60.0, c2_3=-1.0)
+    bad = [[0] * 4 for _ in range(4)]
+    bad[1][0] = 7
+    worst, v = diag.link_grade(m, bad=bad)
+    by = {(x["src"], x["dst"]): x for x in v}
+    assert worst == 20
+    assert by[(2, 3)]["health"] == 20 and by[(2, 3)]["message"] == "no peer access"
+    assert by[(1, 0)]["health"] == 20 and by[(1, 0)]["message"] == "7 corrupt 16-byte words"
+    assert sum(1 for x in v if x["health"]) == 2
+    # a pair without access is not a sibling: the median is over measured links only
+    assert by[(0, 1)]["sibling_median_gbps"] == pytest.approx(60.0)
+
+    # one GPU: nothing to grade, and not an error
+    assert diag.link_grade([[0.0]], floor_gbps=38.0) == (0, [])
+    # two GPUs: one sibling is no population, only the floor applies
+    worst, v = diag.link_grade([[0, 60.0], [20.0, 0]])
+    assert worst == 0 and all(x["sibling_median_gbps"] == 0 for x in v)
+    worst, v = diag.link_grade([[0, 60.0], [20.0, 0]], floor_gbps=38.0)
+    assert worst == 20 and [x["health"] for x in v] == [0, 20]
+    # three GPUs: the other five links are the population
+    worst, v = diag.link_grade(_matrix(3, 50.0, c0_1=30.0))
+    assert worst == 20 and sum(1 for x in v if x["health"]) == 1
+
+
+def test_link_test_without_a_gpu_is_an_error_not_a_crash():
+    import torch
+    from k8s_gpu_monitor_amd.ops import diag
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(diag.DiagError):
+        diag.link_test("uni", devices=[0])
