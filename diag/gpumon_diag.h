@@ -241,6 +241,11 @@ typedef struct {
 } gmd_link_config_t;
 GMD_API int gmd_link_test(const gmd_link_config_t* cfg, int mode, double* gbps, uint64_t* bad);
 
+/* The link test's copy and check kernels run inside one GPU (local memory to local memory): proves the kernels on a
+ * host where no peer is visible.  bytes need not be a multiple of the kernel's stride; *bad counts wrong words and a
+ * touched guard word past the end. */
+GMD_API int gmd_link_selftest(int device, uint64_t bytes, int workgroups, double* gbps, uint64_t* bad);
+
 /* Grading of a link matrix, host arithmetic only (no GPU needed).  A pair fails when it has no peer access,
  * delivered corrupt data, runs below the absolute floor, or below fail_ratio of the median of the other pairs;
  * it warns below warn_ratio of that median.  The sibling median needs at least two other measured pairs;

@@ -258,6 +258,44 @@ int gmd_link_test(const gmd_link_config_t* cfg_in, int mode, double* gbps, uint6
   return GMD_OK;
 }
 
+int gmd_link_selftest(int device, uint64_t bytes, int workgroups, double* gbps, uint64_t* bad) {
+  if (!gbps || !bad) return GMD_ERR_BADPARAM;
+  const uint64_t words = std::max<uint64_t>(1, (bytes ? bytes : 256ull << 20) / 16);
+  const int grid = workgroups > 0 ? std::min(workgroups, 4096) : 64;
+  GMD_HIP(hipSetDevice(device));
+  gmd::DeviceBuffer src, dst, cnt;
+  int rc;
+  // one guard word past the destination: the kernel must leave it alone
+  if ((rc = src.alloc(words * 16)) || (rc = dst.alloc((words + 1) * 16)) || (rc = cnt.alloc(sizeof(unsigned long long)))) return rc;
+  link_fill_kernel<<<gmd::stream_grid(words, 256, 4), 256>>>((u32x4*)src.p, words, 5u);
+  GMD_HIP(hipMemset(dst.p, 0xa5, (words + 1) * 16));
+  GMD_HIP(hipMemset(cnt.p, 0, sizeof(unsigned long long)));
+  hipEvent_t e0, e1;
+  GMD_HIP(hipEventCreate(&e0));
+  GMD_HIP(hipEventCreate(&e1));
+  link_copy_kernel<<<grid, 256>>>((const u32x4*)src.p, (u32x4*)dst.p, words);
+  GMD_HIP(hipEventRecord(e0, nullptr));
+  for (int k = 0; k < 5; k++) link_copy_kernel<<<grid, 256>>>((const u32x4*)src.p, (u32x4*)dst.p, words);
+  GMD_HIP(hipEventRecord(e1, nullptr));
+  GMD_HIP(hipGetLastError());
+  GMD_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GMD_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *gbps = ms > 0 ? (double)words * 16 * 5 / (ms * 1e-3) / 1e9 : 0;
+  link_check_kernel<<<gmd::stream_grid(words, 256, 4), 256>>>((const u32x4*)dst.p, words, 5u, (unsigned long long*)cnt.p);
+  GMD_HIP(hipGetLastError());
+  unsigned long long v = 0;
+  uint32_t guard[4];
+  GMD_HIP(hipMemcpy(&v, cnt.p, sizeof v, hipMemcpyDeviceToHost));
+  GMD_HIP(hipMemcpy(guard, (char*)dst.p + words * 16, 16, hipMemcpyDeviceToHost));
+  for (uint32_t g : guard)
+    if (g != 0xa5a5a5a5u) v++;
+  *bad = v;
+  return GMD_OK;
+}
+
 int gmd_link_grade(int ndev, const double* gbps, const uint64_t* bad, const gmd_link_rule_t* rule_in,
                    gmd_link_verdict_t* out, int* n_out) {
   if (ndev < 1 || !gbps || !out || !n_out) return GMD_ERR_BADPARAM;

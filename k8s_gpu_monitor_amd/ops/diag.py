@@ -293,6 +293,17 @@ def link_test(mode="uni", devices=None, bytes=256 << 20, iters=5, verify=True, w
     return [[m[i * n + j] for j in range(n)] for i in range(n)], [[b[i * n + j] for j in range(n)] for i in range(n)]
 
 
+def link_selftest(bytes=256 << 20, workgroups=0, device=0):
+    """The link test's copy + check kernels inside one GPU: (gbps, bad_words)."""
+    L = _lib()
+    L.gmd_link_selftest.argtypes = [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    g, b = C.c_double(), C.c_uint64()
+    rc = L.gmd_link_selftest(device, bytes, workgroups, C.byref(g), C.byref(b))
+    if rc:
+        raise DiagError(rc, "gmd_link_selftest")
+    return g.value, b.value
+
+
 def link_grade(gbps, bad=None, floor_gbps=0.0, warn_ratio=0.0, fail_ratio=0.0):
     """Grades a link matrix (host arithmetic, no GPU): returns (worst_health, [verdict dict per ordered pair]).
     Health is 0 pass / 10 warn / 20 fail; a pair fails without peer access, with corrupt data, under the absolute

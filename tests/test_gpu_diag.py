@@ -315,6 +315,27 @@ def test_rccl_sweep_single_gpu(diag):
         diag.rccl_sweep(devices=[0, 0])
 
 
+def test_link_test_kernels_and_the_one_gpu_case(diag):
+    """The peer-store and check kernels inside one GPU (sizes that are and are not a multiple of the kernel's stride,
+    with a guard word behind the destination), and the link test on a host with one GPU: a 1x1 matrix, no error."""
+    import json
+    import subprocess
+    from conftest import bin_path
+    for nbytes, wgs in ((64 << 20, 0), ((64 << 20) + 16 * 777, 64), (16 * 1000, 7), (16, 64), (256 << 20, 256)):
+        gbps, bad = diag.link_selftest(bytes=nbytes, workgroups=wgs)
+        assert bad == 0, (nbytes, wgs, bad)
+    gbps, bad = diag.link_selftest(bytes=1 << 30, workgroups=64)
+    assert bad == 0 and gbps > 200, gbps   # 64 workgroups are a quarter of the chip; local HBM is no bottleneck for a link
+    for mode in diag.LINK_MODES:
+        assert diag.link_test(mode, devices=[0]) == ([[0.0]], [[0]])
+    with pytest.raises(diag.DiagError):
+        diag.link_test("uni", devices=[0, 0])
+    r = subprocess.run([bin_path("gpumon-diag"), "links", "--json"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    doc = json.loads(r.stdout)
+    assert doc["result"] == "pass" and doc["links"] == {"gpus": 1, "tested": 0} and doc["verdicts"] == []
+
+
 def test_cli_report_is_published_and_exported(tmp_path):
     """gpumon-diag run -r 1 --publish -> gpumon-exporter --diag-results -> gpumon_diag_* series."""
     import os
