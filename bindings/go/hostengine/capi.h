@@ -20,6 +20,14 @@ static inline void he_health(gm_health_response_t* p, int n) {
   for (int i = 0; i < n; i++) p[i].version = GM_HEALTH_RESPONSE_VERSION;
 }
 
+static inline void he_thresholds(gm_health_thresholds_t* p) { memset(p, 0, sizeof *p); p->version = GM_HEALTH_THRESHOLDS_VERSION; }
+static inline void he_diag_result(gm_diag_result_t* p) { memset(p, 0, sizeof *p); p->version = GM_DIAG_RESULT_VERSION; }
+static inline void he_copy_str(char* dst, size_t cap, const char* src) {
+  if (!cap) return;
+  strncpy(dst, src, cap - 1);
+  dst[cap - 1] = 0;
+}
+
 static inline int64_t he_value_i64(const gm_value_t* v) { return v->v.i64; }
 static inline double he_value_dbl(const gm_value_t* v) { return v->v.dbl; }
 static inline const char* he_value_str(const gm_value_t* v) { return v->v.str; }

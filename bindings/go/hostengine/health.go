@@ -95,3 +95,34 @@ func healthCheckByGpuID(gpuID uint) (DeviceHealth, error) {
 	}
 	return res[0], nil
 }
+
+// HealthThresholds are the levels the health checks compare against.  The reference has
+// no such knob: its levels live inside the closed engine.  Defaults suit MI355X-class parts.
+type HealthThresholds struct {
+	HotspotWarnC, HotspotFailC int
+	MemWarnC, MemFailC         int
+	BadPagesFail               int
+	CeBurstWarn                int
+	PowerOverCapWarn           float64
+}
+
+func GetHealthThresholds() (HealthThresholds, error) {
+	var t C.gm_health_thresholds_t
+	C.he_thresholds(&t)
+	if err := check("health thresholds get", C.gm_health_thresholds_get(&t)); err != nil {
+		return HealthThresholds{}, err
+	}
+	return HealthThresholds{HotspotWarnC: int(t.hotspot_warn_c), HotspotFailC: int(t.hotspot_fail_c), MemWarnC: int(t.mem_warn_c),
+		MemFailC: int(t.mem_fail_c), BadPagesFail: int(t.bad_pages_fail), CeBurstWarn: int(t.ce_burst_warn),
+		PowerOverCapWarn: float64(t.power_over_cap_warn)}, nil
+}
+
+func SetHealthThresholds(h HealthThresholds) error {
+	var t C.gm_health_thresholds_t
+	C.he_thresholds(&t)
+	t.hotspot_warn_c, t.hotspot_fail_c = C.int32_t(h.HotspotWarnC), C.int32_t(h.HotspotFailC)
+	t.mem_warn_c, t.mem_fail_c = C.int32_t(h.MemWarnC), C.int32_t(h.MemFailC)
+	t.bad_pages_fail, t.ce_burst_warn = C.int32_t(h.BadPagesFail), C.int32_t(h.CeBurstWarn)
+	t.power_over_cap_warn = C.double(h.PowerOverCapWarn)
+	return check("health thresholds set", C.gm_health_thresholds_set(&t))
+}

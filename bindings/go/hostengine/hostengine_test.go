@@ -193,6 +193,60 @@ func TestProcessInfoAndIntrospection(t *testing.T) {
 	}
 }
 
+func TestLinksThresholdsAndDiagResultsOnFake(t *testing.T) {
+	defer withFake(t, "gpus=8,seed=1,steady=1")()
+	links, err := GetXgmiLinks(2)
+	if err != nil || len(links) != 7 {
+		t.Fatalf("links: %v %v", links, err)
+	}
+	peers := map[uint]bool{}
+	for _, l := range links {
+		if l.Up == nil || !*l.Up || l.PeerGPU == nil || *l.PeerGPU == 2 || l.PeerBusID == "" {
+			t.Errorf("link %d: %+v", l.Link, l)
+			continue
+		}
+		peers[*l.PeerGPU] = true
+	}
+	if len(peers) != 7 {
+		t.Errorf("a full mesh has seven distinct peers: %v", peers)
+	}
+
+	th, err := GetHealthThresholds()
+	if err != nil || th.HotspotFailC != 110 || th.MemWarnC != 95 {
+		t.Fatalf("default thresholds: %+v %v", th, err)
+	}
+	th.HotspotWarnC = 60
+	if err := SetHealthThresholds(th); err != nil {
+		t.Fatal(err)
+	}
+	if got, _ := GetHealthThresholds(); got.HotspotWarnC != 60 {
+		t.Errorf("thresholds not kept: %+v", got)
+	}
+	th.HotspotWarnC, th.HotspotFailC = 120, 110
+	if err := SetHealthThresholds(th); err == nil {
+		t.Error("warn above fail must be refused")
+	}
+
+	if err := SubmitDiagResult(1, "xgmi_p2p", HealthXGMI, DiagFail, 41.0, "link 3 to GPU 4: 41.0 GB/s"); err != nil {
+		t.Fatal(err)
+	}
+	res, err := GetDiagResults(1)
+	if err != nil || len(res) != 1 || res[0].Health != "Failure" || res[0].Value == nil || math.Abs(*res[0].Value-41.0) > 1e-9 {
+		t.Fatalf("diag results: %+v %v", res, err)
+	}
+	h, err := HealthCheckByGpuId(1)
+	if err != nil || h.Status != "Failure" {
+		t.Fatalf("a failed diagnostic must fail the health check: %+v %v", h, err)
+	}
+	found := false
+	for _, w := range h.Watches {
+		found = found || strings.Contains(w.Error, "link 3 to GPU 4")
+	}
+	if !found {
+		t.Errorf("incident text missing: %+v", h.Watches)
+	}
+}
+
 func TestStartHostengineMode(t *testing.T) {
 	cleanup, err := Init(StartHostengine, "", "fake", "gpus=2")
 	if err != nil {

@@ -214,6 +214,29 @@ func peerLink(a, b uint) (*rawPeerLink, error) {
 		busID: C.GoString(&p.pci_bdf[0]), maxBandwidthMBs: int64(p.max_bw_mbs)}, nil
 }
 
+type rawXgmiLink struct {
+	link                 uint
+	state, peer          int
+	peerBusID            string
+	bitRate, maxBw       int64
+	rxKB, txKB           int64
+}
+
+func xgmiLinks(idx uint) ([]rawXgmiLink, error) {
+	var raw [C.GM_MAX_XGMI_LINKS]C.gm_xgmi_link_t
+	n := C.int(C.GM_MAX_XGMI_LINKS)
+	if err := check("xgmi links", C.gm_smi_xgmi_links(C.uint32_t(idx), &raw[0], &n)); err != nil {
+		return nil, err
+	}
+	out := make([]rawXgmiLink, 0, int(n))
+	for i := 0; i < int(n); i++ {
+		l := &raw[i]
+		out = append(out, rawXgmiLink{link: uint(l.link), state: int(l.state), peer: int(l.peer_gpu), peerBusID: C.GoString(&l.peer_bdf[0]),
+			bitRate: int64(l.bit_rate_gbps), maxBw: int64(l.max_bandwidth_gbps), rxKB: int64(l.rx_kb), txKB: int64(l.tx_kb)})
+	}
+	return out, nil
+}
+
 func linkName(link, hops uint) string { return C.GoString(C.gm_link_type_name(C.int32_t(link), C.uint32_t(hops))) }
 func linkDescription(link uint) string { return C.GoString(C.gm_link_type_description(C.int32_t(link))) }
 

@@ -391,6 +391,38 @@ func GetXGMILink(dev1, dev2 *Device) (connected bool, links uint, err error) {
 	return strings.HasPrefix(name, "XGMI"), l.numLinks, nil
 }
 
+// XgmiLink is one physical link of a device, as the reference's per-link walk over
+// NvLinkState / NvLinkRemotePciInfo reports it (bindings/go/nvml/bindings.go:268-318).
+type XgmiLink struct {
+	Link       uint
+	Up         *bool   // nil: not wired or not reported
+	PeerIndex  *uint   // device index at the far end
+	PeerBusID  string  // empty when unknown
+	BitRateGbs *uint   // per lane
+	MaxBwGbs   *uint   // advertised, one direction
+	RxKB, TxKB *uint64 // cumulative
+}
+
+// GetXGMILinks lists every link of the device with its far end.
+func (d *Device) GetXGMILinks() ([]XgmiLink, error) {
+	raw, err := xgmiLinks(d.Index)
+	if err != nil {
+		return nil, err
+	}
+	out := make([]XgmiLink, 0, len(raw))
+	for _, l := range raw {
+		x := XgmiLink{Link: l.link, PeerIndex: optUint(int64(l.peer), l.peer >= 0), PeerBusID: l.peerBusID,
+			BitRateGbs: optUint(l.bitRate, l.bitRate >= 0), MaxBwGbs: optUint(l.maxBw, l.maxBw >= 0),
+			RxKB: optU64(l.rxKB, l.rxKB >= 0), TxKB: optU64(l.txKB, l.txKB >= 0)}
+		if l.state >= 0 {
+			up := l.state != 0
+			x.Up = &up
+		}
+		out = append(out, x)
+	}
+	return out, nil
+}
+
 func (d *Device) GetDeviceMode() (*DeviceMode, error) {
 	m, err := deviceMode(d.Index)
 	if err != nil {
