@@ -19,7 +19,7 @@ CORE_SRC := core/common/util.cc core/common/json.cc core/fields.cc \
             core/backend/fake_backend.cc core/backend/amdsmi_backend.cc core/backend/replicate_backend.cc \
             core/engine/engine.cc core/engine/health.cc core/engine/policy.cc core/engine/accounting.cc \
             core/rpc/wire.cc core/rpc/server.cc core/rpc/client.cc \
-            core/exporter/http.cc core/exporter/exporter.cc core/exporter/podmap.cc core/exporter/kubelet.cc core/exporter/diag_results.cc \
+            core/exporter/http.cc core/exporter/exporter.cc core/exporter/podmap.cc core/exporter/kubelet.cc core/exporter/diag_results.cc core/prof/prof_child.cc \
             core/exporter/views.cc core/exporter/rest.cc core/exporter/pod_exporter.cc core/capi.cc core/smi.cc
 CORE_OBJ := $(CORE_SRC:%.cc=$(BUILD)/obj/%.o)
 BINS     := gpumon gpumon-exporter gpumon-hostengine gpumon-pod-exporter

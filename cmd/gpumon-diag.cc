@@ -377,7 +377,7 @@ int cmd_mfma(const Args& a, Report& r) {
 // Matrix-pipe activity during a soak, from the MFMA busy-cycle hardware counter.  The counter plugin cannot
 // live in a process that runs HIP work (core/prof/prof_counters.h), so `gpumon-prof-probe` runs as a child and
 // its lines are read from a pipe: "agent N: name  pci dddd:bb:dd.f ..." once, then per 250 ms window
-// "agent N window Ws gpu_active X mfma_active Y clock_mhz Z ...".
+// "agent N window Ws GRBM_NAME X (K instances) mfma_active Y clock_mhz Z ...".
 struct MfmaWatch {
   pid_t pid = -1;
   int fd = -1;
@@ -432,11 +432,12 @@ struct MfmaWatch {
       char line[1024];
       while (fgets(line, sizeof line, f)) {
         int agent = 0;
-        char name[64], bdf[32];
+        char name[64], bdf[32], grbm[64];
+        int inst = 0;
         double w, ga, ma, mz;
         std::lock_guard<std::mutex> l(mu);
         if (sscanf(line, "agent %d: %63s pci %31s", &agent, name, bdf) == 3) bdf_of[agent] = bdf;
-        else if (sscanf(line, "agent %d window %lfs gpu_active %lf mfma_active %lf clock_mhz %lf", &agent, &w, &ga, &ma, &mz) == 5) {
+        else if (sscanf(line, "agent %d window %lfs %63s %lf (%d instances) mfma_active %lf clock_mhz %lf", &agent, &w, grbm, &ga, &inst, &ma, &mz) == 7) {
           mfma[agent].push_back(ma);
           mhz[agent].push_back(mz);
           at[agent].push_back(now());

@@ -5,9 +5,12 @@
 //
 //   -e               run the host engine inside this process (embedded)
 //   -p               also export the five profiling metrics
-//   --prof-counters  with -e: feed dcgm_fi_prof_pipe_tensor_active from the MFMA pipe's hardware counter
-//                    (loads libgpumon_prof.so: rocprofiler-sdk device counting + HSA inside this process;
-//                    same as GPUMON_PROF_COUNTERS=1; implies -p)
+//   --prof-counters[=child]  with -e: feed dcgm_fi_prof_pipe_tensor_active, dcgm_fi_prof_sm_active and
+//                    gpumon_prof_mem_pipe_active from hardware counters; implies -p.  Plain: libgpumon_prof.so inside
+//                    this process (rocprofiler-sdk device counting + HSA; continuous windows; = GPUMON_PROF_COUNTERS=1).
+//                    =child: a short-lived `gpumon-prof-probe --once` every --prof-period seconds takes the windows, so
+//                    this process never opens the compute runtime (sampled values; = GPUMON_PROF_COUNTERS=child)
+//   --prof-period S  seconds between probe runs with --prof-counters=child (default 10; = GPUMON_PROF_PERIOD_S)
 //   -o FILE          publish atomically to FILE (default /run/prometheus/dcgm.prom; "" disables)
 //   -d MS            collection interval, >= 100 (default 1000)
 //   --listen ADDR    serve /metrics, /gpu/metrics, /healthz (e.g. :9400)
@@ -69,6 +72,8 @@ int main(int argc, char** argv) {
     else if (a == "-e") embedded = true;
     else if (a == "-p") profiling = true;
     else if (a == "--prof-counters") { profiling = true; setenv("GPUMON_PROF_COUNTERS", "1", 1); }
+    else if (a == "--prof-counters=child") { profiling = true; setenv("GPUMON_PROF_COUNTERS", "child", 1); }
+    else if (a == "--prof-period") { val(&tmp); setenv("GPUMON_PROF_PERIOD_S", tmp.c_str(), 1); }
     else if (a == "-o") val(&out);
     else if (a == "-d") { val(&tmp); interval = atol(tmp.c_str()); }
     else if (a == "--listen") val(&listen);

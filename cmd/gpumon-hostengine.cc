@@ -4,7 +4,9 @@
 //   --domain-socket PATH   serve clients on a unix socket
 //   -b ADDR / --port N     serve clients on TCP (default 127.0.0.1:5555)
 //   --http ADDR            also serve REST + /metrics (e.g. :8070)
-//   --prof-counters        MFMA pipe activity from hardware counters (libgpumon_prof.so; = GPUMON_PROF_COUNTERS=1)
+//   --prof-counters[=child] matrix-pipe, CU and memory-pipeline activity from hardware counters: in this process
+//                          (libgpumon_prof.so; = GPUMON_PROF_COUNTERS=1) or sampled by a short-lived probe child
+//                          every --prof-period seconds (= GPUMON_PROF_COUNTERS=child, GPUMON_PROF_PERIOD_S)
 //   --backend NAME --backend-spec SPEC
 //   --pid-file FILE        default /run/gpumon-hostengine.pid when writable, else /tmp
 //   --daemon               detach from the terminal
@@ -41,6 +43,8 @@ int main(int argc, char** argv) {
     else if (a == "--port" || a == "-p") { val(&tmp); port = atoi(tmp.c_str()); }
     else if (a == "--http") val(&http);
     else if (a == "--prof-counters") setenv("GPUMON_PROF_COUNTERS", "1", 1);
+    else if (a == "--prof-counters=child") setenv("GPUMON_PROF_COUNTERS", "child", 1);
+    else if (a == "--prof-period") { val(&tmp); setenv("GPUMON_PROF_PERIOD_S", tmp.c_str(), 1); }
     else if (a == "--pid-file") { val(&pid_file); pid_file_set = true; }
     else if (a == "--daemon") daemonize = true;
     else if (a == "-n") daemonize = false;

@@ -25,6 +25,7 @@
 #include <amd_smi/amdsmi.h>
 
 #include "../common/util.h"
+#include "../prof/prof_child.h"
 #include "../prof/prof_counters.h"
 #include "backend.h"
 
@@ -157,7 +158,13 @@ struct Dev {
   // Counter plugin (libgpumon_prof.so): agent of this device, last window's MFMA activity.
   int prof_agent = -1;
   int64_t prof_read_mono = 0;
-  double mfma_active = std::nan("");
+  // Last window of each counter-derived value; the in-process plugin measures one GRBM signal per window, so
+  // every value carries the time it was taken and goes blank when it is older than a few windows.
+  struct ProfValue {
+    double v = std::nan("");
+    int64_t mono = 0;
+  };
+  ProfValue mfma_active, cu_active, mem_pipe_active, gpu_active_ctr;
 };
 
 // Entry points of the optional counter plugin (core/prof/prof_counters.h), resolved at run time.
@@ -168,6 +175,8 @@ struct ProfApi {
   decltype(&::gmp_sample) sample = nullptr;
   decltype(&::gmp_last_error) last_error = nullptr;
   decltype(&::gmp_close) close = nullptr;
+  decltype(&::gmp_abi_version) abi_version = nullptr;
+  decltype(&::gmp_set_count) set_count = nullptr;
 };
 
 std::string sysfs_trim(const std::string& path) {
@@ -245,6 +254,7 @@ class AmdSmiBackend : public Backend {
       if (d.events_on && api_.amdsmi_stop_gpu_event_notification) api_.amdsmi_stop_gpu_event_notification(d.h);
     api_.amdsmi_shut_down();
     if (prof_.close) prof_.close();
+    prof_child_.reset();
     prof_tried_ = false;  // a later init maps the plugin's agents onto the new device table
     inited_ = false;
     devs_.clear();
@@ -1020,13 +1030,21 @@ class AmdSmiBackend : public Backend {
       }
       if (!std::isnan(d.occupancy)) out->set_d(GM_FI_PROF_CU_OCCUPANCY, d.occupancy);
       else out->set_blank(GM_FI_PROF_CU_OCCUPANCY, GM_VS_NOT_SUPPORTED);
-      // Wave-level CU activity has no device-wide source (the SQ's wave counters only see the waves of the
-      // process that programs them): blank, not estimated.  MFMA pipe activity comes from the counter
-      // plugin when the operator has switched it on, and is blank otherwise.
-      out->set_blank(GM_FI_PROF_CU_ACTIVE, GM_VS_NOT_SUPPORTED);
-      const double mfma = sample_prof_counters(d);
-      if (!std::isnan(mfma)) out->set_d(GM_FI_PROF_MFMA_ACTIVE, mfma);
-      else out->set_blank(GM_FI_PROF_MFMA_ACTIVE, GM_VS_NOT_SUPPORTED);
+      // The SQ's wave counters only see the waves of the process that programs them, so CU activity is taken from
+      // the GRBM block, which is device-wide: the share of cycles the wave launcher of an XCC had work in flight,
+      // averaged over the XCCs.  It, the memory-pipeline figure and MFMA pipe activity come from the counter
+      // plugin when the operator has switched it on, and are blank otherwise.
+      sample_prof_counters(d);
+      auto put = [&](uint16_t id, const Dev::ProfValue& pv) {
+        // a value is kept for as long as its source takes to come round again (child period or set rotation), plus slack
+        if (!std::isnan(pv.v) && now - pv.mono <= prof_keep_us_) out->set_d(id, pv.v);
+        else out->set_blank(id, GM_VS_NOT_SUPPORTED);
+      };
+      put(GM_FI_PROF_MFMA_ACTIVE, d.mfma_active);
+      put(GM_FI_PROF_CU_ACTIVE, d.cu_active);
+      put(GM_FI_PROF_MEM_PIPE_ACTIVE, d.mem_pipe_active);
+      // the firmware's own busy figure wins; the counter fills in where the metrics table has none
+      if (std::isnan(gr_active)) put(GM_FI_PROF_GR_ENGINE_ACTIVE, d.gpu_active_ctr);
     }
     return true;
   }
@@ -1037,6 +1055,18 @@ class AmdSmiBackend : public Backend {
     prof_tried_ = true;
     const char* on = getenv("GPUMON_PROF_COUNTERS");
     if (!on || !*on || !strcmp(on, "0")) return;
+    if (!strcmp(on, "child")) {
+      // Sampled mode: a short-lived child takes the windows (core/prof/prof_child.h); this process never opens
+      // the compute runtime.
+      const char* pe = getenv("GPUMON_PROF_PERIOD_S");
+      const char* we = getenv("GPUMON_PROF_WINDOW_MS");
+      const double period = pe && atof(pe) > 0 ? atof(pe) : 10.0;
+      prof_child_.reset(new ProfChildSampler("", period, we && atoi(we) > 0 ? atoi(we) : 250));
+      prof_child_->start();
+      prof_keep_us_ = (int64_t)(3.0 * std::max(1.0, period) * 1e6) + 2000000;
+      GM_LOGI("profiling counters on: one %s --once every %.0f s", ProfChildSampler::default_probe().c_str(), period);
+      return;
+    }
     // A process that runs HIP work of its own cannot host the plugin: once the plugin has registered and opened
     // HSA, the HIP runtime of the same process finds no device.  Leave the field blank there.
     for (const char* hip : {"libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"})
@@ -1065,6 +1095,13 @@ class AmdSmiBackend : public Backend {
     prof_.sample = reinterpret_cast<decltype(prof_.sample)>(dlsym(prof_.lib, "gmp_sample"));
     prof_.last_error = reinterpret_cast<decltype(prof_.last_error)>(dlsym(prof_.lib, "gmp_last_error"));
     prof_.close = reinterpret_cast<decltype(prof_.close)>(dlsym(prof_.lib, "gmp_close"));
+    prof_.abi_version = reinterpret_cast<decltype(prof_.abi_version)>(dlsym(prof_.lib, "gmp_abi_version"));
+    prof_.set_count = reinterpret_cast<decltype(prof_.set_count)>(dlsym(prof_.lib, "gmp_set_count"));
+    if (!prof_.abi_version || !prof_.set_count || prof_.abi_version() != GMP_ABI_VERSION) {
+      GM_LOGW("profiling counters unavailable: libgpumon_prof.so has another layout of gmp_sample_t than this library");
+      prof_.sample = nullptr;
+      return;
+    }
     char err[256] = "";
     int n = -1;
     if (!prof_.open || !prof_.agent_info || !prof_.sample || !prof_.last_error || !prof_.close || (n = prof_.open(err, sizeof err)) < 0) {
@@ -1083,24 +1120,43 @@ class AmdSmiBackend : public Backend {
         taken[(size_t)a] = true;
         break;
       }
-    GM_LOGI("profiling counters on: %d agent(s) through rocprofiler-sdk", n);
+    prof_sets_ = std::max(1, prof_.set_count());
+    GM_LOGI("profiling counters on: %d agent(s) through rocprofiler-sdk, %d counter sets in rotation", n, prof_sets_);
   }
 
-  double sample_prof_counters(Dev& d) {
+  void sample_prof_counters(Dev& d) {
     if (!prof_tried_) load_prof_plugin();
-    if (!prof_.sample || d.prof_agent < 0) return std::nan("");
     const int64_t now = monotonic_us();
-    if (d.prof_read_mono && now - d.prof_read_mono < 100000) return d.mfma_active;  // one window per 100 ms at most
+    auto take = [&](Dev::ProfValue& pv, double v, int64_t at) {
+      if (!std::isnan(v)) pv.v = v, pv.mono = at;
+    };
+    if (prof_child_) {
+      ProfWindow w;
+      if (!prof_child_->latest(d.st.pci_bdf, &w)) return;  // the values age out by themselves
+      take(d.mfma_active, w.mfma_active, w.taken_mono_us);
+      take(d.cu_active, w.cu_active, w.taken_mono_us);
+      take(d.mem_pipe_active, w.mem_pipe_active, w.taken_mono_us);
+      take(d.gpu_active_ctr, w.gpu_active, w.taken_mono_us);
+      return;
+    }
+    if (!prof_.sample || d.prof_agent < 0) return;
+    if (d.prof_read_mono && now - d.prof_read_mono < 100000) return;  // one window per 100 ms at most
+    // Each window measures one of the rotating signals: a value stays good for two rotations of the sets.
+    const int64_t since = d.prof_read_mono ? now - d.prof_read_mono : 1000000;
+    prof_keep_us_ = std::max<int64_t>(prof_keep_us_, 2 * prof_sets_ * since + 500000);
     d.prof_read_mono = now;
     gmp_sample_t s;
     const int rc = prof_.sample(d.prof_agent, &s);
-    if (rc == 0) d.mfma_active = s.mfma_active;
-    else if (rc < 0) {
-      d.mfma_active = std::nan("");
+    if (rc == 0) {
+      take(d.mfma_active, s.mfma_active, now);
+      take(d.cu_active, s.cu_active, now);
+      take(d.mem_pipe_active, s.mem_pipe_active, now);
+      take(d.gpu_active_ctr, s.gpu_active, now);
+    } else if (rc < 0) {
+      d.mfma_active = d.cu_active = d.mem_pipe_active = d.gpu_active_ctr = Dev::ProfValue();
       if (!prof_warned_) GM_LOGW("profiling counters: %s", prof_.last_error());
       prof_warned_ = true;
     }
-    return d.mfma_active;
   }
 
   bool sample_vram(Dev& d, Sample* out) {
@@ -1257,6 +1313,9 @@ class AmdSmiBackend : public Backend {
   std::thread pcie_thread_;
   ProfApi prof_;
   bool prof_tried_ = false, prof_warned_ = false;
+  int prof_sets_ = 1;
+  int64_t prof_keep_us_ = 3000000;
+  std::unique_ptr<ProfChildSampler> prof_child_;
   std::vector<Dev> devs_;
 };
 

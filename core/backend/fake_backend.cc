@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "../common/util.h"
+#include "../prof/prof_child.h"
 #include "backend.h"
 
 namespace gpumon {
@@ -282,6 +283,26 @@ class FakeBackend : public Backend {
       out->set_d(GM_FI_PROF_CU_OCCUPANCY, load * 0.4);
       out->set_d(GM_FI_PROF_MFMA_ACTIVE, load * 0.7);
       out->set_d(GM_FI_PROF_HBM_ACTIVE, load * 0.6);
+      out->set_d(GM_FI_PROF_MEM_PIPE_ACTIVE, load * 0.5);
+      // $GPUMON_PROF_COUNTERS=child: the counter-derived values come from the short-lived probe child, exactly as
+      // with the real device library (the probe is whatever $GPUMON_PROF_PROBE names); blank until it has reported.
+      if (const char* e = getenv("GPUMON_PROF_COUNTERS"); e && !strcmp(e, "child")) {
+        if (!prof_child_) {
+          const char* pe = getenv("GPUMON_PROF_PERIOD_S");
+          const char* we = getenv("GPUMON_PROF_WINDOW_MS");
+          prof_child_.reset(new ProfChildSampler("", pe && atof(pe) > 0 ? atof(pe) : 10.0, we && atoi(we) > 0 ? atoi(we) : 250));
+          prof_child_->start();
+        }
+        ProfWindow w;
+        const bool have = prof_child_->latest(g.st.pci_bdf, &w);
+        auto put = [&](uint16_t id, double v) {
+          if (have && !std::isnan(v)) out->set_d(id, v);
+          else out->set_blank(id, GM_VS_NOT_SUPPORTED);
+        };
+        put(GM_FI_PROF_MFMA_ACTIVE, w.mfma_active);
+        put(GM_FI_PROF_CU_ACTIVE, w.cu_active);
+        put(GM_FI_PROF_MEM_PIPE_ACTIVE, w.mem_pipe_active);
+      }
     }
     if (failing) out->blank_untouched(failing, GM_VS_ERROR);
 
@@ -500,6 +521,7 @@ class FakeBackend : public Backend {
 
  private:
   uint32_t ngpus_ = 8, seed_ = 1;
+  std::unique_ptr<ProfChildSampler> prof_child_;
   bool fail_init_ = false, events_supported_ = true, topology_unsupported_ = false, steady_ = false;
   std::string partition_mode_;
   double default_load_ = 0;

@@ -2,11 +2,11 @@
 // device counting service.  See prof_counters.h for why this is a library of its own.
 //
 // One counting context per GPU agent, created inside the tool-initialisation callback
-// (the only place rocprofiler-sdk lets a context be created), each with one counter
-// configuration of three hardware counters: GRBM_COUNT and GRBM_GUI_ACTIVE (both of the
-// two GRBM slots) and SQ_VALU_MFMA_BUSY_CYCLES (one of the eight SQ slots).  A sample reads
-// the counters, stops the context and starts it again, so every window begins from zero
-// and a reader needs no deltas.
+// (the only place rocprofiler-sdk lets a context be created), with a few counter
+// configurations it rotates through: each holds GRBM_COUNT and ONE busy signal of the GRBM
+// block (it has two slots) plus SQ_VALU_MFMA_BUSY_CYCLES (one of the eight SQ slots).  A
+// sample reads the counters, stops the context, switches to the next configuration and
+// starts again, so every window begins from zero and a reader needs no deltas.
 //
 // What is and is not device-wide (measured on MI355X, ROCm 7.2, with the load in another
 // process): the GRBM counters and the MFMA pipe's busy cycles count all work on the device;
@@ -34,25 +34,33 @@
 
 namespace {
 
-enum Slot { kCount = 0, kGuiActive, kMfmaBusy, kExtra0, kExtra1, kExtra2, kSlots };
+enum Slot { kCount = 0, kGrbm, kMfmaBusy, kExtra0, kExtra1, kExtra2, kSlots };
 // The last three are for looking at other SQ counters with gpumon-prof-probe ($GPUMON_PROF_EXTRA=A,B,C, summed
 // over their instances); nothing is derived from them.
 std::string g_extra[3];
-const char* counter_name(int s) {
-  static const char* const names[] = {"GRBM_COUNT", "GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"};
-  return s < kExtra0 ? names[s] : g_extra[s - kExtra0].c_str();
+// Rotation of the second GRBM slot, one entry per counter set.
+std::vector<std::string> g_grbm = {"GRBM_GUI_ACTIVE", "GRBM_SPI_BUSY", "GRBM_TA_BUSY"};
+std::string slot_counter(int set, int s) {
+  if (s == kCount) return "GRBM_COUNT";
+  if (s == kGrbm) return g_grbm[(size_t)set];
+  if (s == kMfmaBusy) return "SQ_VALU_MFMA_BUSY_CYCLES";
+  return g_extra[s - kExtra0];
 }
-// How the instances of a counter (one per XCC / shader engine / ...) fold into one number: the two GRBM
-// counters tick once per clock in every XCC (take the largest), the SQ counters add up over the chip.
-const bool kSum[kSlots] = {false, false, true, true, true, true};
 
-struct Agent {
-  rocprofiler_agent_v0_t info;
-  rocprofiler_context_id_t ctx{};
+// One counter configuration: GRBM_COUNT, one rotating GRBM counter, the matrix-pipe counter, the extras.
+struct Set {
   rocprofiler_counter_config_id_t cfg{};
   std::map<uint64_t, int> slot_of;  // counter id -> Slot
   bool have[kSlots] = {};
   size_t max_records = 0;
+};
+
+struct Agent {
+  rocprofiler_agent_v0_t info;
+  rocprofiler_context_id_t ctx{};
+  std::vector<Set> sets;
+  std::vector<std::string> set_names;  // the rotating GRBM counter of each set
+  size_t active = 0;  // the set the running window counts
   bool running = false;
   std::chrono::steady_clock::time_point started;
 };
@@ -84,7 +92,7 @@ void set_err(const char* fmt, ...) {
 void set_config_cb(rocprofiler_context_id_t ctx, rocprofiler_agent_id_t, rocprofiler_device_counting_agent_cb_t set_config,
                    void* user) {
   auto* a = static_cast<Agent*>(user);
-  if (a && a->cfg.handle) set_config(ctx, a->cfg);
+  if (a && a->active < a->sets.size() && a->sets[a->active].cfg.handle) set_config(ctx, a->sets[a->active].cfg);
 }
 
 int setup_agent(Agent& a) {
@@ -97,24 +105,44 @@ int setup_agent(Agent& a) {
         return ROCPROFILER_STATUS_SUCCESS;
       },
       &all));
-  std::vector<rocprofiler_counter_id_t> want;
+  struct Known {
+    rocprofiler_counter_id_t id;
+    std::string name;
+    size_t instances;
+  };
+  std::vector<Known> known;
   for (auto& c : all) {
     rocprofiler_counter_info_v1_t ci;
-    if (rocprofiler_query_counter_info(c, ROCPROFILER_COUNTER_INFO_VERSION_1, &ci) != ROCPROFILER_STATUS_SUCCESS || !ci.name)
-      continue;
-    for (int s = 0; s < kSlots; s++)
-      if (!a.have[s] && !strcmp(ci.name, counter_name(s))) {
-        a.have[s] = true;
-        a.slot_of[c.handle] = s;
-        a.max_records += ci.dimensions_instances_count;
-        want.push_back(c);
-      }
+    if (rocprofiler_query_counter_info(c, ROCPROFILER_COUNTER_INFO_VERSION_1, &ci) == ROCPROFILER_STATUS_SUCCESS && ci.name)
+      known.push_back({c, ci.name, ci.dimensions_instances_count});
   }
-  if (!a.have[kCount] || !a.have[kGuiActive]) {
-    set_err("agent %s has no GRBM_COUNT / GRBM_GUI_ACTIVE counter", a.info.name ? a.info.name : "?");
+  for (size_t k = 0; k < g_grbm.size(); k++) {
+    Set set;
+    std::vector<rocprofiler_counter_id_t> want;
+    for (int s = 0; s < kSlots; s++) {
+      const std::string name = slot_counter((int)k, s);
+      if (name.empty()) continue;
+      for (auto& c : known)
+        if (!set.have[s] && c.name == name) {
+          set.have[s] = true;
+          set.slot_of[c.id.handle] = s;
+          set.max_records += c.instances;
+          want.push_back(c.id);
+        }
+    }
+    if (!set.have[kCount]) {
+      set_err("agent %s has no GRBM_COUNT counter", a.info.name ? a.info.name : "?");
+      return -1;
+    }
+    if (!set.have[kGrbm]) continue;  // a name this device does not know: leave the set out
+    RP(rocprofiler_create_counter_config(a.info.id, want.data(), want.size(), &set.cfg));
+    a.sets.push_back(std::move(set));
+    a.set_names.push_back(g_grbm[k]);
+  }
+  if (a.sets.empty()) {
+    set_err("agent %s knows none of the GRBM busy counters asked for", a.info.name ? a.info.name : "?");
     return -1;
   }
-  RP(rocprofiler_create_counter_config(a.info.id, want.data(), want.size(), &a.cfg));
   RP(rocprofiler_create_context(&a.ctx));
   RP(rocprofiler_configure_device_counting_service(a.ctx, rocprofiler_buffer_id_t{0}, a.info.id, set_config_cb, &a));
   return 0;
@@ -129,6 +157,16 @@ int tool_init(rocprofiler_client_finalize_t, void*) {
       g_extra[i] = all.substr(0, c);
       all = c == std::string::npos ? std::string() : all.substr(c + 1);
     }
+  }
+  if (const char* e = getenv("GPUMON_PROF_GRBM"); e && *e) {
+    g_grbm.clear();
+    std::string all = e;
+    while (!all.empty() && g_grbm.size() < 8) {
+      const size_t c = all.find(',');
+      if (c != 0) g_grbm.push_back(all.substr(0, c));
+      all = c == std::string::npos ? std::string() : all.substr(c + 1);
+    }
+    if (g_grbm.empty()) g_grbm = {"GRBM_GUI_ACTIVE"};
   }
   std::vector<rocprofiler_agent_v0_t> gpus;
   rocprofiler_status_t st = rocprofiler_query_available_agents(
@@ -230,51 +268,70 @@ int gmp_sample(int agent, gmp_sample_t* out) {
     a.started = now;
     return 1;
   }
-  std::vector<rocprofiler_counter_record_t> rec(a.max_records + 16);
+  const Set& set = a.sets[a.active];
+  const std::string grbm_name = a.set_names[a.active];
+  std::vector<rocprofiler_counter_record_t> rec(set.max_records + 16);
   size_t n = rec.size();
   rocprofiler_status_t st =
       rocprofiler_sample_device_counting_service(a.ctx, rocprofiler_user_data_t{}, ROCPROFILER_COUNTER_FLAG_NONE, rec.data(), &n);
   const double window_s = std::chrono::duration<double>(now - a.started).count();
-  static const bool keep_running = getenv("GPUMON_PROF_KEEP_RUNNING") != nullptr;  // experiment: no stop/start between windows
-  if (!keep_running || st != ROCPROFILER_STATUS_SUCCESS) {
-    // Restart whatever the read said, so that one bad read does not end the series.
-    rocprofiler_stop_context(a.ctx);
-    a.running = false;
-    if (rocprofiler_start_context(a.ctx) == ROCPROFILER_STATUS_SUCCESS) {
-      a.running = true;
-      a.started = std::chrono::steady_clock::now();
-    }
-  } else {
-    a.started = now;
+  // Stop, move on to the next counter set, start: every window begins from zero, and one bad read does not end
+  // the series.  (The configuration callback runs inside the start and picks sets[active].)
+  rocprofiler_stop_context(a.ctx);
+  a.running = false;
+  a.active = (a.active + 1) % a.sets.size();
+  if (rocprofiler_start_context(a.ctx) == ROCPROFILER_STATUS_SUCCESS) {
+    a.running = true;
+    a.started = std::chrono::steady_clock::now();
   }
   if (st != ROCPROFILER_STATUS_SUCCESS) {
     set_err("rocprofiler_sample_device_counting_service: %s", rocprofiler_get_status_string(st));
     return -1;
   }
+  // The GRBM counters have one instance per XCC: GRBM_COUNT ticks once a clock in each (take the largest), the
+  // busy counter is averaged over its instances, so one busy XCC of eight reads 12.5 %, not 100 %.  The SQ
+  // counters add up over the chip.
   double v[kSlots] = {};
+  int grbm_instances = 0;
   for (size_t i = 0; i < n; i++) {
     rocprofiler_counter_id_t cid{};
     if (rocprofiler_query_record_counter_id(rec[i].id, &cid) != ROCPROFILER_STATUS_SUCCESS) continue;
-    auto it = a.slot_of.find(cid.handle);
-    if (it == a.slot_of.end()) continue;
+    auto it = set.slot_of.find(cid.handle);
+    if (it == set.slot_of.end()) continue;
     const int s = it->second;
-    v[s] = kSum[s] ? v[s] + rec[i].counter_value : std::max(v[s], rec[i].counter_value);
+    if (s == kCount) v[s] = std::max(v[s], rec[i].counter_value);
+    else v[s] += rec[i].counter_value;
+    if (s == kGrbm) grbm_instances++;
   }
   const double nan = std::nan("");
-  memset(out->raw, 0, sizeof out->raw);
+  memset(out, 0, sizeof *out);
   for (int s = 0; s < kSlots; s++) out->raw[s] = v[s];
   out->window_s = window_s;
-  out->gpu_active = out->mfma_active = out->clock_mhz = nan;
+  out->gpu_active = out->mfma_active = out->clock_mhz = out->cu_active = out->mem_pipe_active = out->grbm_busy = nan;
+  snprintf(out->grbm_name, sizeof out->grbm_name, "%s", grbm_name.c_str());
+  out->grbm_instances = grbm_instances;
   const double cycles = v[kCount];
   if (cycles <= 0) return 0;  // a window without a clock tick: nothing to divide by
   auto pct = [](double x) { return x < 0 ? 0.0 : x > 100 ? 100.0 : x; };
-  out->gpu_active = pct(100.0 * v[kGuiActive] / cycles);
+  if (grbm_instances > 0) {
+    out->grbm_busy = pct(100.0 * v[kGrbm] / (grbm_instances * cycles));
+    if (grbm_name == "GRBM_GUI_ACTIVE") out->gpu_active = out->grbm_busy;
+    else if (grbm_name == "GRBM_SPI_BUSY") out->cu_active = out->grbm_busy;
+    else if (grbm_name == "GRBM_TA_BUSY") out->mem_pipe_active = out->grbm_busy;
+  }
   if (window_s > 0) out->clock_mhz = cycles / window_s / 1e6;
   // SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs (the normalisation of rocprofiler-sdk's MfmaUtil,
   // taken over all cycles of the window instead of the busy ones).
   const double simds = a.info.simd_count;
-  if (a.have[kMfmaBusy] && simds > 0) out->mfma_active = pct(100.0 * v[kMfmaBusy] / (simds * cycles));
+  if (set.have[kMfmaBusy] && simds > 0) out->mfma_active = pct(100.0 * v[kMfmaBusy] / (simds * cycles));
   return 0;
+}
+
+int gmp_abi_version(void) { return GMP_ABI_VERSION; }
+
+int gmp_set_count(void) {
+  std::lock_guard<std::mutex> l(g_mu);
+  return g_open && !g_agents.empty() ? (int)g_agents[0].sets.size() : 0;
 }
 
 const char* gmp_last_error(void) { return g_err.c_str(); }

@@ -28,19 +28,34 @@ typedef struct gmp_agent_info_t {
   char name[64];
 } gmp_agent_info_t;
 
-// Percent of wall-clock time over the window since the previous gmp_sample of the same
-// agent; NAN for a value the counters of this device cannot give.
+// The GRBM block has two counter slots.  One holds GRBM_COUNT (the clock every ratio is taken over); the other
+// rotates from window to window through a list of device-wide busy signals ($GPUMON_PROF_GRBM, default
+// GRBM_GUI_ACTIVE,GRBM_SPI_BUSY,GRBM_TA_BUSY), so a sample carries ONE of gpu_active / cu_active /
+// mem_pipe_active and NAN for the others; the matrix-pipe counter lives in the SQ block and is in every window.
+//
+// Percent of wall-clock time over the window since the previous gmp_sample of the same agent; NAN for a value
+// this window did not measure or the counters of this device cannot give.
+#define GMP_ABI_VERSION 2
 typedef struct gmp_sample_t {
-  double window_s;     // length of the window
-  double gpu_active;   // graphics engine busy (GRBM_GUI_ACTIVE / GRBM_COUNT)
-  double mfma_active;  // matrix pipe busy, averaged over SIMDs and over all cycles of the window
-  double clock_mhz;    // shader clock the device held (GRBM_COUNT / window)
-  double raw[8];       // folded counter values: GRBM_COUNT, GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES, then the $GPUMON_PROF_EXTRA ones
+  double window_s;         // length of the window
+  double gpu_active;       // graphics engine busy (GRBM_GUI_ACTIVE / GRBM_COUNT)
+  double mfma_active;      // matrix pipe busy, averaged over SIMDs and over all cycles of the window
+  double clock_mhz;        // shader clock the device held (GRBM_COUNT / window)
+  double cu_active;        // wave launcher / shader arrays busy (GRBM_SPI_BUSY / GRBM_COUNT, mean over the counter's instances)
+  double mem_pipe_active;  // vector-memory address units busy (GRBM_TA_BUSY / GRBM_COUNT, mean over instances)
+  double grbm_busy;        // this window's rotating counter as a percentage, whatever it was
+  char grbm_name[32];      // ... and its name
+  int32_t grbm_instances;  // instances the rotating counter reported (one per XCC on MI355X)
+  int32_t reserved;
+  double raw[8];           // folded counter values: GRBM_COUNT, the rotating GRBM counter (summed over instances), SQ_VALU_MFMA_BUSY_CYCLES, then the $GPUMON_PROF_EXTRA ones
 } gmp_sample_t;
 
 // Registers with rocprofiler-sdk, opens HSA, sets up one counting context per GPU agent.
 // Returns the number of GPU agents (>= 0) or a negative value with a message in err.
+GMP_API int gmp_abi_version(void);  // GMP_ABI_VERSION the library was built with
 GMP_API int gmp_open(char* err, int errlen);
+// Number of counter sets the windows rotate through (valid after gmp_open).
+GMP_API int gmp_set_count(void);
 GMP_API int gmp_agent_info(int agent, gmp_agent_info_t* out);
 // First call for an agent starts its counters and returns 1 (no window yet); later calls
 // return 0 and fill *out, or a negative value with a message from gmp_last_error().

@@ -230,6 +230,7 @@ enum {
   GM_FI_PROF_CU_OCCUPANCY = 1003,
   GM_FI_PROF_MFMA_ACTIVE = 1004,
   GM_FI_PROF_HBM_ACTIVE = 1005,
+  GM_FI_PROF_MEM_PIPE_ACTIVE = 1020, /* vector-memory address units busy, % (hardware counters only) */
   GM_FI_XCD_BUSY_0 = 1100, /* ..1107 per-XCD gfx busy % */
 
   GM_FI_MAX_ID = 1200

@@ -1,5 +1,6 @@
 """Device-wide hardware counters (build/libgpumon_prof.so, core/prof/prof_counters.h): MFMA pipe
-activity, graphics-engine activity and the shader clock held, per window, for work of ANY process.
+activity, graphics-engine / shader-array / memory-pipeline activity and the shader clock held, per window,
+for work of ANY process.
 
 The plugin registers with rocprofiler-sdk and opens the compute runtime (HSA) itself.  Use it from a
 monitoring process that does not run HIP work of its own (what ``gpumon-exporter --prof-counters``
@@ -25,7 +26,11 @@ class _AgentInfo(C.Structure):
 
 class _Sample(C.Structure):
     _fields_ = [("window_s", C.c_double), ("gpu_active", C.c_double), ("mfma_active", C.c_double), ("clock_mhz", C.c_double),
-                ("raw", C.c_double * 8)]
+                ("cu_active", C.c_double), ("mem_pipe_active", C.c_double), ("grbm_busy", C.c_double), ("grbm_name", C.c_char * 32),
+                ("grbm_instances", C.c_int32), ("reserved", C.c_int32), ("raw", C.c_double * 8)]
+
+
+ABI_VERSION = 2
 
 
 _L = None
@@ -35,7 +40,10 @@ def _lib():
     global _L
     if _L is None:
         L = C.CDLL(_find("libgpumon_prof.so"), mode=C.RTLD_LOCAL)
+        if not hasattr(L, "gmp_abi_version") or L.gmp_abi_version() != ABI_VERSION:
+            raise ProfError("libgpumon_prof.so was built for another layout of gmp_sample_t: rebuild it (make prof)")
         L.gmp_open.argtypes, L.gmp_open.restype = [C.c_char_p, C.c_int], C.c_int
+        L.gmp_set_count.argtypes, L.gmp_set_count.restype = [], C.c_int
         L.gmp_agent_info.argtypes, L.gmp_agent_info.restype = [C.c_int, C.POINTER(_AgentInfo)], C.c_int
         L.gmp_sample.argtypes, L.gmp_sample.restype = [C.c_int, C.POINTER(_Sample)], C.c_int
         L.gmp_last_error.argtypes, L.gmp_last_error.restype = [], C.c_char_p
@@ -61,10 +69,17 @@ def open():  # noqa: A001 - mirrors gmp_open
     return agents
 
 
+def set_count():
+    """Counter sets the windows rotate through: after this many samples every metric has been measured once."""
+    return _lib().gmp_set_count()
+
+
 def sample(agent=0):
     """One window: None on the first call for an agent (it only starts the counters), then a dict with
-    ``window_s``, ``gpu_active``, ``mfma_active`` (percent of all cycles of the window), ``clock_mhz`` and
-    the raw counter values; a value the device cannot give is None, never 0."""
+    ``window_s``, ``mfma_active`` (percent of all cycles of the window), ``clock_mhz`` and ONE of ``gpu_active`` /
+    ``cu_active`` / ``mem_pipe_active``: the GRBM block has two counter slots, one holds the clock, the other rotates
+    from window to window (``grbm_name`` says which it was).  A value the window did not measure or the device
+    cannot give is None, never 0."""
     s = _Sample()
     rc = _lib().gmp_sample(agent, C.byref(s))
     if rc < 0:
@@ -72,8 +87,34 @@ def sample(agent=0):
     if rc == 1:
         return None
     opt = lambda v: None if math.isnan(v) else v  # noqa: E731
-    return {"window_s": s.window_s, "gpu_active": opt(s.gpu_active), "mfma_active": opt(s.mfma_active), "clock_mhz": opt(s.clock_mhz),
-            "raw": {"GRBM_COUNT": s.raw[0], "GRBM_GUI_ACTIVE": s.raw[1], "SQ_VALU_MFMA_BUSY_CYCLES": s.raw[2]}}
+    name = s.grbm_name.decode()
+    return {"window_s": s.window_s, "gpu_active": opt(s.gpu_active), "cu_active": opt(s.cu_active),
+            "mem_pipe_active": opt(s.mem_pipe_active), "mfma_active": opt(s.mfma_active), "clock_mhz": opt(s.clock_mhz),
+            "grbm_name": name, "grbm_busy": opt(s.grbm_busy), "grbm_instances": s.grbm_instances,
+            "raw": {"GRBM_COUNT": s.raw[0], name: s.raw[1], "SQ_VALU_MFMA_BUSY_CYCLES": s.raw[2]}}
+
+
+def sample_all(agent=0, window_s=0.25, sleep=None):
+    """One window per counter set, merged: every metric the device can give, each from its own window."""
+    import time
+    sleep = sleep or time.sleep
+    merged, mfma = {}, []
+    if sample(agent) is not None:
+        pass  # counters were already running: that window's length is unknown to the caller, drop it
+    for _ in range(max(1, set_count())):
+        sleep(window_s)
+        w = sample(agent)
+        if w is None:
+            continue
+        for k in ("gpu_active", "cu_active", "mem_pipe_active", "clock_mhz"):
+            if w[k] is not None:
+                merged[k] = w[k]
+        if w["mfma_active"] is not None:
+            mfma.append(w["mfma_active"])
+    merged["mfma_active"] = sum(mfma) / len(mfma) if mfma else None
+    for k in ("gpu_active", "cu_active", "mem_pipe_active", "clock_mhz"):
+        merged.setdefault(k, None)
+    return merged
 
 
 def close():

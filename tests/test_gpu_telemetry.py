@@ -375,9 +375,7 @@ time.sleep(0.5)
 idle = prof.sample(0)
 print(json.dumps({"agents": agents, "idle": idle}), flush=True)
 sys.stdin.readline()          # the parent starts its load, then asks for windows
-prof.sample(0)
-time.sleep(1.0)
-busy = prof.sample(0)
+busy = prof.sample_all(0, window_s=0.4)    # one window per counter set: every metric from its own window
 prof.close()
 print(json.dumps({"busy": busy}), flush=True)
 """
@@ -388,7 +386,7 @@ print(json.dumps({"busy": busy}), flush=True)
     try:
         first = json.loads(p.stdout.readline())
         assert first["agents"] and first["agents"][0]["cu_count"] == 256 and first["agents"][0]["simd_count"] == 1024
-        assert first["idle"]["mfma_active"] < 5.0, first
+        assert first["idle"]["mfma_active"] < 5.0 and first["idle"]["grbm_name"] == "GRBM_GUI_ACTIVE", first
         a, b = (torch.randn(8192, 8192, device="cuda:0").bfloat16() for _ in range(2))
         c = torch.empty(8192, 8192, dtype=torch.bfloat16, device="cuda:0")
         stream = torch.cuda.current_stream().cuda_stream
@@ -404,6 +402,9 @@ print(json.dumps({"busy": busy}), flush=True)
         busy = json.loads(p.stdout.readline())["busy"]
         assert busy["mfma_active"] > 40.0 and busy["gpu_active"] > 90.0, busy
         assert 1000 < busy["clock_mhz"] < 2600, busy
+        # the shader arrays and the memory pipeline of a GEMM that streams its operands are both busy
+        assert busy["cu_active"] is not None and busy["cu_active"] > 50.0, busy
+        assert busy["mem_pipe_active"] is not None and busy["mem_pipe_active"] > 20.0, busy
         assert p.wait(timeout=30) == 0
     finally:
         if p.poll() is None:

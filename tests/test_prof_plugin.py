@@ -63,3 +63,86 @@ def test_python_wrapper_refuses_politely_without_a_device():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "refused:" in r.stdout, (r.stdout, r.stderr)
+
+
+# --------------------------------------------------- sampled mode: probe child --
+def _exporter_with_probe(tmp_path, script_body, period="1"):
+    probe = tmp_path / "probe.sh"
+    probe.write_text("#!/bin/sh\n" + script_body)
+    probe.chmod(0o755)
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=2,seed=3,steady=1", GPUMON_PROF_PROBE=str(probe),
+               GPUMON_PROF_PERIOD_S=period)
+    p = subprocess.Popen([binary("gpumon-exporter"), "-e", "--prof-counters=child", "-o", "", "-d", "200", "--listen", "127.0.0.1:0"],
+                         stderr=subprocess.PIPE, text=True, env=env)
+    port = None
+    for _ in range(100):
+        line = p.stderr.readline()
+        m = re.search(r"Serving /metrics on port (\d+)", line or "")
+        if m:
+            port = int(m.group(1))
+            break
+    assert port
+    return p, port
+
+
+def _scrape(port):
+    return promparse.parse(urllib.request.urlopen(f"http://127.0.0.1:{port}/metrics", timeout=5).read().decode())
+
+
+def test_child_mode_exports_what_the_probe_measured_and_blanks_the_rest(tmp_path):
+    """--prof-counters=child: the daemon starts `probe --once --interval-ms N` every period and exports the line of
+    each GPU under that GPU (matched by PCI address); a GPU the probe did not report and a value it printed as nan
+    are absent from the scrape, never 0."""
+    log = tmp_path / "calls.log"
+    body = (f'echo "$@" >> {log}\n'
+            'echo "agents: 1"\n'
+            'echo "sample pci=0000:05:00.0 window_s=0.750 gpu_active=99.1 cu_active=77.25 mem_pipe_active=nan mfma_active=42.5 clock_mhz=1934"\n')
+    p, port = _exporter_with_probe(tmp_path, body)
+    try:
+        deadline = time.time() + 10
+        fam = {}
+        while time.time() < deadline:
+            fam = _scrape(port)
+            if "dcgm_fi_prof_pipe_tensor_active" in fam and fam["dcgm_fi_prof_pipe_tensor_active"].samples:
+                break
+            time.sleep(0.3)
+        tensor = {l["gpu"]: v for l, v in fam["dcgm_fi_prof_pipe_tensor_active"].samples}
+        sm = {l["gpu"]: v for l, v in fam["dcgm_fi_prof_sm_active"].samples}
+        assert tensor == {"0": 42.5} and sm == {"0": 77.25}, (tensor, sm)
+        assert "gpumon_prof_mem_pipe_active" not in fam or not fam["gpumon_prof_mem_pipe_active"].samples
+        assert len(fam["dcgm_fi_prof_gr_engine_active"].samples) == 2  # not counter-derived on this backend
+        time.sleep(2.5)
+        calls = log.read_text().splitlines()
+        assert len(calls) >= 2 and all(c.startswith("--once --interval-ms ") for c in calls), calls
+    finally:
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=15)
+
+
+def test_child_mode_survives_a_failing_and_a_hanging_probe(tmp_path):
+    """A probe that fails gives blanks, not a crash and not stale numbers; a probe that never ends is killed with
+    the daemon (the exact child, by pid)."""
+    p, port = _exporter_with_probe(tmp_path, 'echo "gmp_open: no device" >&2\nexit 1\n')
+    try:
+        time.sleep(2.0)
+        fam = _scrape(port)
+        assert "dcgm_fi_prof_pipe_tensor_active" not in fam or not fam["dcgm_fi_prof_pipe_tensor_active"].samples
+        assert len(fam["dcgm_gpu_temp"].samples) == 2
+    finally:
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=15) == 0
+    pidfile = tmp_path / "probe.pid"
+    p, port = _exporter_with_probe(tmp_path, f'echo $$ > {pidfile}\nexec sleep 300\n')
+    try:
+        for _ in range(50):
+            if pidfile.exists() and pidfile.read_text().strip():
+                break
+            time.sleep(0.1)
+        child = int(pidfile.read_text())
+        assert len(_scrape(port)["dcgm_gpu_temp"].samples) == 2  # the sampler thread waits, the exporter does not
+    finally:
+        t0 = time.time()
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=15) == 0 and time.time() - t0 < 5
+    time.sleep(0.2)
+    assert not os.path.exists(f"/proc/{child}") or open(f"/proc/{child}/stat").read().split()[2] == "Z"
