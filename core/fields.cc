@@ -141,7 +141,7 @@ std::vector<FieldDef> build_table() {
     {GM_FI_PROF_CU_ACTIVE,        DBL, SRC_PROF, "prof_cu_active", "%", GAUGE, 1, "dcgm_fi_prof_sm_active", "The ratio of cycles an SM has at least 1 warp assigned (in %).", nullptr, 0},
     {GM_FI_PROF_CU_OCCUPANCY,     DBL, SRC_PROF, "prof_cu_occupancy", "%", GAUGE, 1, "dcgm_fi_prof_sm_occupancy", "The ratio of number of warps resident on an SM (in %).", nullptr, 0},
     {GM_FI_PROF_MFMA_ACTIVE,      DBL, SRC_PROF, "prof_mfma_active", "%", GAUGE, 1, "dcgm_fi_prof_pipe_tensor_active", "Ratio of cycles the tensor (HMMA) pipe is active (in %).", nullptr, 0},
-    {GM_FI_PROF_MEM_PIPE_ACTIVE,  DBL, SRC_PROF, "prof_mem_pipe_active", "%", GAUGE, 1, "gpumon_prof_mem_pipe_active", "Ratio of cycles the vector-memory address units have work in flight (in %).", nullptr, 0},
+    {GM_FI_PROF_MEM_PIPE_ACTIVE,  DBL, SRC_PROF, "prof_mem_pipe_active", "%", GAUGE, 2, "gpumon_prof_mem_pipe_active", "Ratio of cycles the vector-memory address units have work in flight (in %).", nullptr, 0},
     {GM_FI_PROF_HBM_ACTIVE,       DBL, SRC_PROF, "prof_hbm_active", "%", GAUGE, 1, "dcgm_fi_prof_dram_active", "Ratio of cycles the device memory interface is active sending or receiving data (in %).", nullptr, 0},
   };
 

@@ -43,7 +43,7 @@ sys.path.insert(0, os.getcwd())
 from k8s_gpu_monitor_amd._lib import binary
 from k8s_gpu_monitor_amd.utils import promparse
 env = dict(os.environ, GPUMON_PROF_PERIOD_S="10")
-p = subprocess.Popen([binary("gpumon-exporter"), "-e", "--prof-counters=child", "-o", "", "-d", "1000", "--self-metrics", "--listen", "127.0.0.1:0"],
+p = subprocess.Popen([binary("gpumon-exporter"), "-e", "--prof-counters=child", "--extras", "-o", "", "-d", "1000", "--self-metrics", "--listen", "127.0.0.1:0"],
                      stderr=subprocess.PIPE, text=True, env=env)
 port = None
 for _ in range(100):
