@@ -13,7 +13,8 @@ P=build/bin/gpumon-prof-probe
 D=build/bin/gpumon-diag
 
 probe() {  # probe <tag>
-  /usr/bin/time -f "probe_cost user %U sys %S wall %e" timeout -k 5 40 $P --once --interval-ms 300 > "$OUT/$1.default.log" 2> "$OUT/$1.default.err" || return 1
+  local TIMEFORMAT="probe_cost user %U sys %S wall %R"
+  { time timeout -k 5 40 $P --once --interval-ms 300 > "$OUT/$1.default.log"; } 2> "$OUT/$1.default.err" || return 1
   GPUMON_PROF_GRBM=GRBM_EA_BUSY,GRBM_TC_BUSY,GRBM_CP_BUSY timeout -k 5 40 $P --interval-ms 300 --count 3 > "$OUT/$1.other.log" 2> "$OUT/$1.other.err" || return 1
   GPUMON_PROF_GRBM=GRBM_SPI_BUSY,GRBM_TA_BUSY,GRBM_GUI_ACTIVE timeout -k 5 40 $P --interval-ms 300 --count 3 > "$OUT/$1.raw.log" 2> "$OUT/$1.raw.err" || return 1
   echo "== $1"; grep '^sample' "$OUT/$1.default.log"; grep probe_cost "$OUT/$1.default.err"
