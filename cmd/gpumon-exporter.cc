@@ -10,7 +10,7 @@
 //                    this process (rocprofiler-sdk device counting + HSA; continuous windows; = GPUMON_PROF_COUNTERS=1).
 //                    =child: a short-lived `gpumon-prof-probe --once` every --prof-period seconds takes the windows, so
 //                    this process never opens the compute runtime (sampled values; = GPUMON_PROF_COUNTERS=child)
-//   --prof-period S  seconds between probe runs with --prof-counters=child (default 10; = GPUMON_PROF_PERIOD_S)
+//   --prof-period S  seconds between probe runs with --prof-counters=child (default 30: one probe run costs about 0.3 s of CPU; = GPUMON_PROF_PERIOD_S)
 //   -o FILE          publish atomically to FILE (default /run/prometheus/dcgm.prom; "" disables)
 //   -d MS            collection interval, >= 100 (default 1000)
 //   --listen ADDR    serve /metrics, /gpu/metrics, /healthz (e.g. :9400)

@@ -156,6 +156,7 @@ struct Dev {
   int64_t occupancy_read_mono = 0;
   double occupancy = std::nan("");
   // Counter plugin (libgpumon_prof.so): agent of this device, last window's MFMA activity.
+  int64_t throttle_bits = 0;
   int prof_agent = -1;
   int64_t prof_read_mono = 0;
   // Last window of each counter-derived value; the in-process plugin measures one GRBM signal per window, so
@@ -992,22 +993,28 @@ class AmdSmiBackend : public Backend {
       const bool any_host = device_residency(host_xcc, AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC, &host);
       if (any_low) out->set_i(GM_FI_LOW_UTIL_VIOLATION, us(low)); else out->set_blank(GM_FI_LOW_UTIL_VIOLATION, GM_VS_NOT_SUPPORTED);
       if (any_host) out->set_i(GM_FI_RELIABILITY_VIOLATION, us(host)); else out->set_blank(GM_FI_RELIABILITY_VIOLATION, GM_VS_NOT_SUPPORTED);
-      // Active reasons = accumulators that moved since the previous sample.
-      int64_t bits = 0;
-      if (d.have_prev) {
-        static const int64_t bit_of[5] = {GM_THROTTLE_POWER, GM_THROTTLE_THERMAL, GM_THROTTLE_HBM_THERMAL,
-                                          GM_THROTTLE_VR_THERMAL, GM_THROTTLE_PROCHOT};
-        for (int i = 0; i < 5; i++)
-          if (valid(res[i]) && res[i] > d.prev_res[i]) bits |= bit_of[i];
-        if (any_low && low > d.prev_low) bits |= GM_THROTTLE_LOW_UTIL;
-        if (any_host && host > d.prev_host) bits |= GM_THROTTLE_HOST_LIMIT;
+      // Active reasons = accumulators that moved between two DISTINCT firmware tables.  The firmware refreshes the
+      // table on its own cadence (about once a second); a watch faster than that reads the same table several
+      // times, and comparing equal tables would clear every reason between refreshes.
+      const bool fresh = !d.have_prev || !valid(m.accumulation_counter) || m.accumulation_counter != d.prev_acc_counter;
+      if (fresh) {
+        int64_t bits = 0;
+        if (d.have_prev) {
+          static const int64_t bit_of[5] = {GM_THROTTLE_POWER, GM_THROTTLE_THERMAL, GM_THROTTLE_HBM_THERMAL,
+                                            GM_THROTTLE_VR_THERMAL, GM_THROTTLE_PROCHOT};
+          for (int i = 0; i < 5; i++)
+            if (valid(res[i]) && res[i] > d.prev_res[i]) bits |= bit_of[i];
+          if (any_low && low > d.prev_low) bits |= GM_THROTTLE_LOW_UTIL;
+          if (any_host && host > d.prev_host) bits |= GM_THROTTLE_HOST_LIMIT;
+        }
+        d.throttle_bits = bits;
+        d.prev_low = any_low ? low : 0;
+        d.prev_host = any_host ? host : 0;
+        for (int i = 0; i < 5; i++) d.prev_res[i] = valid(res[i]) ? res[i] : 0;
+        d.prev_acc_counter = valid(m.accumulation_counter) ? m.accumulation_counter : 0;
+        d.prev_fw_ts = valid(m.firmware_timestamp) ? m.firmware_timestamp : 0;
       }
-      d.prev_low = any_low ? low : 0;
-      d.prev_host = any_host ? host : 0;
-      out->set_i(GM_FI_THROTTLE_STATUS, bits);
-      for (int i = 0; i < 5; i++) d.prev_res[i] = valid(res[i]) ? res[i] : 0;
-      d.prev_acc_counter = valid(m.accumulation_counter) ? m.accumulation_counter : 0;
-      d.prev_fw_ts = valid(m.firmware_timestamp) ? m.firmware_timestamp : 0;
+      out->set_i(GM_FI_THROTTLE_STATUS, d.throttle_bits);
       d.have_prev = true;
     }
 
@@ -1060,7 +1067,7 @@ class AmdSmiBackend : public Backend {
       // the compute runtime.
       const char* pe = getenv("GPUMON_PROF_PERIOD_S");
       const char* we = getenv("GPUMON_PROF_WINDOW_MS");
-      const double period = pe && atof(pe) > 0 ? atof(pe) : 10.0;
+      const double period = pe && atof(pe) > 0 ? atof(pe) : 30.0;
       prof_child_.reset(new ProfChildSampler("", period, we && atoi(we) > 0 ? atoi(we) : 250));
       prof_child_->start();
       prof_keep_us_ = (int64_t)(3.0 * std::max(1.0, period) * 1e6) + 2000000;

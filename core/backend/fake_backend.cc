@@ -290,7 +290,7 @@ class FakeBackend : public Backend {
         if (!prof_child_) {
           const char* pe = getenv("GPUMON_PROF_PERIOD_S");
           const char* we = getenv("GPUMON_PROF_WINDOW_MS");
-          prof_child_.reset(new ProfChildSampler("", pe && atof(pe) > 0 ? atof(pe) : 10.0, we && atoi(we) > 0 ? atoi(we) : 250));
+          prof_child_.reset(new ProfChildSampler("", pe && atof(pe) > 0 ? atof(pe) : 30.0, we && atoi(we) > 0 ? atoi(we) : 250));
           prof_child_->start();
         }
         ProfWindow w;
