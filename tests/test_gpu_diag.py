@@ -80,12 +80,14 @@ def test_stream_rejects_bad_arguments(diag, dev):
 
 
 def test_stream_bandwidth_is_hbm_class(diag):
-    """Loose floors (about half of what the kernels measure) that still rule out a broken launch plan."""
-    r = diag.hbm_stream("read", 2 << 30, iters=5)
-    c = diag.hbm_stream("copy", 2 << 30, iters=5)
-    t = diag.hbm_stream("triad", 2 << 30, iters=5)
-    assert r["verified"] and c["verified"] and t["verified"]
-    assert r["tbps_best"] > 3.5 and c["tbps_best"] > 2.8 and t["tbps_best"] > 2.8, (r, c, t)
+    """Floors at 85 % of what these kernels measure on MI355X with 4 GiB buffers (read 6.98, copy 6.73, triad 6.70,
+    write 7.21 TB/s best of 20: profiles/diag_run3.txt): a launch plan or cache policy that regresses shows up here."""
+    r = diag.hbm_stream("read", 4 << 30, iters=10)
+    c = diag.hbm_stream("copy", 4 << 30, iters=10)
+    t = diag.hbm_stream("triad", 4 << 30, iters=10)
+    w = diag.hbm_stream("write", 4 << 30, iters=10)
+    assert r["verified"] and c["verified"] and t["verified"] and w["verified"]
+    assert r["tbps_best"] > 5.9 and c["tbps_best"] > 5.7 and t["tbps_best"] > 5.7 and w["tbps_best"] > 6.1, (r, c, t, w)
 
 
 # --------------------------------------------------------------------- memtest --
@@ -146,6 +148,9 @@ def test_memtest_driver_with_injection(diag):
     assert seen and seen[-1] == pytest.approx(1.0) and seen == sorted(seen)
     clean = diag.memtest(bytes=1 << 30, patterns=diag.PATTERNS["random"] | diag.PATTERNS["address"])
     assert clean["errors"] == 0 and clean["patterns_run"] == 2 and clean["write_tbps"] > 1.5 and clean["verify_tbps"] > 1.5
+    # at a size where launch overhead no longer shows: 85 % of the 6.3 TB/s the 4 GiB memtest of bench.py measures
+    big = diag.memtest(bytes=8 << 30, patterns=diag.PATTERNS["random"] | diag.PATTERNS["address"])
+    assert big["errors"] == 0 and big["write_tbps"] > 5.3 and big["verify_tbps"] > 5.3, big
 
 
 # ------------------------------------------------------------------- MFMA GEMM --
@@ -299,9 +304,21 @@ def test_gemm_stress_and_pipe_peak(diag):
     g8 = diag.gemm_stress("mxfp8", 4096, 4096, 4096, seconds=0.5)
     assert g8["verified"] == 1 and g8["sdc_mismatches"] == 0 and g8["tflops"] > 600
     p = diag.mfma_peak("bf16", seconds=0.3)
-    assert p["tflops"] > 1500 and 1000 < p["clock_mhz_est"] < 2600, p  # 2.5 PF dense peak at 2.4 GHz
+    assert p["tflops"] > 1900 and 1000 < p["clock_mhz_est"] < 2600, p  # measured 2239 of the 2.5 PF dense peak at 2.4 GHz
     p8 = diag.mfma_peak("mxfp8", seconds=0.3)
-    assert p8["tflops"] > 1.6 * p["tflops"]
+    assert p8["tflops"] > 4100 and p8["tflops"] > 1.8 * p["tflops"], p8   # measured 4859
+
+
+def test_gemm_throughput_floors_at_the_headline_shape(diag):
+    """8192^3, the shape of the bench: floors at 85 % of what these kernels hold in bench.py's step, which is the
+    lower of the places they are measured (bf16 1540-1570, unscaled fp8 2090, MX-fp8 with real scales 2960-3100
+    TFLOP/s: profiles/bench_1gpu.json, profiles/gemm_ab.json); hipBLASLt's bf16 kernel holds 1650 on the same chip
+    (profiles/gemm_vendor_clock.md)."""
+    floors = {"bf16": 1310.0, "fp8": 1780.0, "mxfp8": 2520.0}
+    for dtype, floor in floors.items():
+        g = diag.gemm_stress(dtype, 8192, 8192, 8192, seconds=1.5)
+        assert g["verified"] == 1 and g["sdc_mismatches"] == 0, (dtype, g)
+        assert g["tflops"] > floor, (dtype, g["tflops"], floor)
 
 
 # ---------------------------------------------------------------- interconnect --
