@@ -145,6 +145,12 @@ struct Dev {
   double acc_tick_us = 1000.0;  // PMFW accumulates once per millisecond until measured otherwise
   uint64_t prev_res[5] = {0, 0, 0, 0, 0};
   uint64_t prev_low = 0, prev_host = 0;  // low-utilisation / below-host-limit residency, worst XCC
+  struct Residency {  // one exported duration: power, thermal, board, low utilisation, host limit
+    bool seen = false;
+    uint64_t ticks = 0;
+    double us = 0;
+  };
+  Residency residency[5];
   bool have_prev = false;
   bool events_on = false;
   // RAS records (CPER) cached by the driver: read position, and whether this user may read them at all
@@ -970,11 +976,21 @@ class AmdSmiBackend : public Backend {
       }
       const uint64_t res[5] = {m.ppt_residency_acc, m.socket_thm_residency_acc, m.hbm_thm_residency_acc,
                                m.vr_thm_residency_acc, m.prochot_residency_acc};
-      auto us = [&](uint64_t ticks) { return (int64_t)((double)ticks * d.acc_tick_us); };
-      if (valid(res[0])) out->set_i(GM_FI_POWER_VIOLATION, us(res[0])); else out->set_blank(GM_FI_POWER_VIOLATION, GM_VS_NOT_SUPPORTED);
-      if (valid(res[1]) || valid(res[2])) out->set_i(GM_FI_THERMAL_VIOLATION, us((valid(res[1]) ? res[1] : 0) + (valid(res[2]) ? res[2] : 0)));
+      // Tick counts become durations incrementally: the first reading is priced at the current tick length, every
+      // later one adds its own delta at the tick length measured then.  Re-pricing the whole accumulator whenever the
+      // estimate of the tick length moves would make a duration run backwards.
+      auto us = [&](int slot, uint64_t ticks) {
+        Dev::Residency& r = d.residency[slot];
+        if (!r.seen || ticks < r.ticks) r.us = (double)ticks * d.acc_tick_us;  // first reading, or the firmware restarted the count
+        else r.us += (double)(ticks - r.ticks) * d.acc_tick_us;
+        r.seen = true;
+        r.ticks = ticks;
+        return (int64_t)r.us;
+      };
+      if (valid(res[0])) out->set_i(GM_FI_POWER_VIOLATION, us(0, res[0])); else out->set_blank(GM_FI_POWER_VIOLATION, GM_VS_NOT_SUPPORTED);
+      if (valid(res[1]) || valid(res[2])) out->set_i(GM_FI_THERMAL_VIOLATION, us(1, (valid(res[1]) ? res[1] : 0) + (valid(res[2]) ? res[2] : 0)));
       else out->set_blank(GM_FI_THERMAL_VIOLATION, GM_VS_NOT_SUPPORTED);
-      if (valid(res[3]) || valid(res[4])) out->set_i(GM_FI_BOARD_LIMIT_VIOLATION, us((valid(res[3]) ? res[3] : 0) + (valid(res[4]) ? res[4] : 0)));
+      if (valid(res[3]) || valid(res[4])) out->set_i(GM_FI_BOARD_LIMIT_VIOLATION, us(2, (valid(res[3]) ? res[3] : 0) + (valid(res[4]) ? res[4] : 0)));
       else out->set_blank(GM_FI_BOARD_LIMIT_VIOLATION, GM_VS_NOT_SUPPORTED);
       out->set_blank(GM_FI_SYNC_BOOST_VIOLATION, GM_VS_NOT_SUPPORTED);
       // Low-utilisation and below-host-limit residency are kept per XCC.  The contract metric is a duration of the
@@ -991,8 +1007,8 @@ class AmdSmiBackend : public Backend {
       uint64_t low = 0, host = 0;
       const bool any_low = device_residency(low_xcc, AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC, &low);
       const bool any_host = device_residency(host_xcc, AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC, &host);
-      if (any_low) out->set_i(GM_FI_LOW_UTIL_VIOLATION, us(low)); else out->set_blank(GM_FI_LOW_UTIL_VIOLATION, GM_VS_NOT_SUPPORTED);
-      if (any_host) out->set_i(GM_FI_RELIABILITY_VIOLATION, us(host)); else out->set_blank(GM_FI_RELIABILITY_VIOLATION, GM_VS_NOT_SUPPORTED);
+      if (any_low) out->set_i(GM_FI_LOW_UTIL_VIOLATION, us(3, low)); else out->set_blank(GM_FI_LOW_UTIL_VIOLATION, GM_VS_NOT_SUPPORTED);
+      if (any_host) out->set_i(GM_FI_RELIABILITY_VIOLATION, us(4, host)); else out->set_blank(GM_FI_RELIABILITY_VIOLATION, GM_VS_NOT_SUPPORTED);
       // Active reasons = accumulators that moved between two DISTINCT firmware tables.  The firmware refreshes the
       // table on its own cadence (about once a second); a watch faster than that reads the same table several
       // times, and comparing equal tables would clear every reason between refreshes.

@@ -309,16 +309,32 @@ def test_gemm_stress_and_pipe_peak(diag):
     assert p8["tflops"] > 4100 and p8["tflops"] > 1.8 * p["tflops"], p8   # measured 4859
 
 
-def test_gemm_throughput_floors_at_the_headline_shape(diag):
-    """8192^3, the shape of the bench: floors at 85 % of what these kernels hold in bench.py's step, which is the
-    lower of the places they are measured (bf16 1540-1570, unscaled fp8 2090, MX-fp8 with real scales 2960-3100
-    TFLOP/s: profiles/bench_1gpu.json, profiles/gemm_ab.json); hipBLASLt's bf16 kernel holds 1650 on the same chip
-    (profiles/gemm_vendor_clock.md)."""
-    floors = {"bf16": 1310.0, "fp8": 1780.0, "mxfp8": 2520.0}
-    for dtype, floor in floors.items():
+def test_gemm_throughput_floors_at_the_headline_shape(diag, dev):
+    """8192^3, the shape of the bench.  Back-to-back launches timed with device events: floors at 85 % of what the
+    kernels measure this way (bf16 1600-1635, unscaled fp8 2090, MX-fp8 with real scales 3090-3115 TFLOP/s:
+    profiles/gemm_ab.json; hipBLASLt's bf16 kernel holds 1650 on the same chip, profiles/gemm_vendor_clock.md).
+    The stress driver adds a checksum pass over C after every launch and an fp32 reference check, so its own figure
+    is lower (bf16 1320, fp8 1760, MX-fp8 2420 in a 5 s run): 85 % of those as well."""
+    flop = 2.0 * 8192 ** 3
+    for dtype, launch_floor, stress_floor in (("bf16", 1360.0, 1120.0), ("fp8", 1775.0, 1495.0), ("mxfp8", 2630.0, 2060.0)):
+        G = _Gemm(diag, dev, 8192, 8192, 8192, dtype, seed=7)
+        c = torch.empty(8192, 8192, dtype=torch.bfloat16, device=dev)
+        for _ in range(30):
+            G.launch(c)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 0.0
+        for _ in range(3):
+            e0.record()
+            for _ in range(100):
+                G.launch(c)
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, flop * 100 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        assert best > launch_floor, (dtype, best, launch_floor)
+        del G, c
         g = diag.gemm_stress(dtype, 8192, 8192, 8192, seconds=1.5)
         assert g["verified"] == 1 and g["sdc_mismatches"] == 0, (dtype, g)
-        assert g["tflops"] > floor, (dtype, g["tflops"], floor)
+        assert g["tflops"] > stress_floor, (dtype, g["tflops"], stress_floor)
 
 
 # ---------------------------------------------------------------- interconnect --
