@@ -25,7 +25,7 @@
 
 static int usage() {
   fprintf(stderr,
-          "usage: gpumon <info|discovery|dmon|ps|topo|health|policy|pidinfo|introspect|events|fields|inject> [options]\n"
+          "usage: gpumon <info|discovery|dmon|ps|topo|links|health|diag|policy|pidinfo|introspect|events|fields|inject> [options]\n"
           "       connection: [-connect ADDR [-socket]] [--start-hostengine] [--backend amdsmi|fake] [--backend-spec S]\n");
   return 2;
 }
@@ -381,6 +381,21 @@ int main(int argc, char** argv) {
     std::string s = render_view(GM_VIEW_TOPOLOGY, 0, false, &st);
     if (st == GM_ST_OK) fputs(s.c_str(), stdout); else fprintf(stderr, "error: %s\n", gm_strerror(st));
     rc = st == GM_ST_OK ? 0 : 1;
+  } else if (cmd == "links" || cmd == "diag") {
+    // gpumon links|diag [-g GPU] [--json]: every GPU unless one is named
+    uint32_t n = 0;
+    gm_device_count(&n);
+    const std::string g = opt(args, "-g", "");
+    rc = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      if (!g.empty() && (uint32_t)atoi(g.c_str()) != i) continue;
+      std::string s = render_view(cmd == "links" ? GM_VIEW_LINKS : GM_VIEW_DIAG, i, flag(args, "--json"), &st);
+      if (st == GM_ST_OK) fputs(s.c_str(), stdout);
+      else {
+        fprintf(stderr, "GPU %u: %s\n", i, gm_strerror(st));
+        if (st != GM_ST_NOT_SUPPORTED) rc = 1;
+      }
+    }
   } else if (cmd == "health") rc = cmd_health(args);
   else if (cmd == "policy") rc = cmd_policy(args);
   else if (cmd == "pidinfo") rc = cmd_pidinfo(args);

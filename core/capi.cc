@@ -861,6 +861,8 @@ gm_status_t gm_render_view(int view, uint32_t id, int json, char* out, size_t* l
     case GM_VIEW_PROCESS: st = view_process_info(e, id, json != 0, &text); break;
     case GM_VIEW_HOSTENGINE: st = view_hostengine(e, json != 0, &text); break;
     case GM_VIEW_TOPOLOGY: st = view_topology_matrix(e, &text); break;
+    case GM_VIEW_LINKS: st = view_links(e, id, json != 0, &text); break;
+    case GM_VIEW_DIAG: st = view_diag_results(e, id, json != 0, &text); break;
     default: return GM_ST_BADPARAM;
   }
   if (st != GM_ST_OK) return st;

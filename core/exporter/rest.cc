@@ -100,6 +100,9 @@ bool handle_rest(Engine* e, const HttpRequest& req, HttpResponse* resp) {
       fail(resp, 404, strprintf("no GPU activity recorded for pid %u", pid));
       return true;
     }
+  } else if (seg.size() == 4 && (seg[1] == "links" || seg[1] == "diag") && (seg[2] == "id" || seg[2] == "uuid")) {
+    if (!resolve_gpu(e, seg[2], seg[3], resp, &gpu)) return true;
+    st = seg[1] == "links" ? view_links(e, gpu, json, &body) : view_diag_results(e, gpu, json, &body);
   } else if (seg.size() == 2 && seg[1] == "status") {
     st = view_hostengine(e, json, &body);
   } else if (seg.size() == 2 && seg[1] == "topology") {

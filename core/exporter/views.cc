@@ -428,6 +428,72 @@ gm_status_t view_topology_matrix(Engine* e, std::string* out) {
   return GM_ST_OK;
 }
 
+gm_status_t view_links(Engine* e, uint32_t gpu, bool json, std::string* out) {
+  std::vector<gm_xgmi_link_t> links;
+  gm_status_t st = e->xgmi_links(gpu, &links);
+  if (st != GM_ST_OK) return st;
+  const int n = (int)links.size();
+  auto opt = [](int64_t v) { return v < 0 ? std::string("N/A") : std::to_string(v); };
+  auto jopt = [](int64_t v) { return v < 0 ? std::string("null") : std::to_string(v); };
+  std::string s;
+  if (json) {
+    s = "{\"gpu\":" + std::to_string(gpu) + ",\"links\":[";
+    for (int i = 0; i < n; i++) {
+      const gm_xgmi_link_t& l = links[i];
+      s += std::string(i ? "," : "") + "{\"link\":" + std::to_string(l.link) + ",\"state\":" +
+           (l.state < 0 ? "null" : l.state ? "\"up\"" : "\"down\"") + ",\"peer_gpu\":" + jopt(l.peer_gpu) + ",\"peer_bdf\":" +
+           (l.peer_bdf[0] ? "\"" + std::string(l.peer_bdf) + "\"" : std::string("null")) + ",\"bit_rate_gbps\":" + jopt(l.bit_rate_gbps) +
+           ",\"max_bandwidth_gbps\":" + jopt(l.max_bandwidth_gbps) + ",\"rx_kb\":" + jopt(l.rx_kb) + ",\"tx_kb\":" + jopt(l.tx_kb) + "}";
+    }
+    s += "]}\n";
+  } else {
+    s = strprintf("xGMI links of GPU %u\n%-5s %-6s %-9s %-14s %10s %12s %16s %16s\n", gpu, "Link", "State", "Peer GPU", "Peer bus id", "Gb/s/lane",
+                  "Max Gb/s", "RX KB", "TX KB");
+    for (int i = 0; i < n; i++) {
+      const gm_xgmi_link_t& l = links[i];
+      s += strprintf("%-5u %-6s %-9s %-14s %10s %12s %16s %16s\n", l.link, l.state < 0 ? "N/A" : l.state ? "Up" : "Down",
+                     opt(l.peer_gpu).c_str(), l.peer_bdf[0] ? l.peer_bdf : "N/A", opt(l.bit_rate_gbps).c_str(),
+                     opt(l.max_bandwidth_gbps).c_str(), opt(l.rx_kb).c_str(), opt(l.tx_kb).c_str());
+    }
+    if (!n) s += "(no xGMI link reported)\n";
+  }
+  *out = s;
+  return GM_ST_OK;
+}
+
+gm_status_t view_diag_results(Engine* e, uint32_t gpu, bool json, std::string* out) {
+  std::vector<gm_diag_result_t> res;
+  gm_status_t st = e->diag_results(gpu, &res);
+  if (st != GM_ST_OK) return st;
+  const int n = (int)res.size();
+  std::string s;
+  if (json) {
+    s = "{\"gpu\":" + std::to_string(gpu) + ",\"results\":[";
+    for (int i = 0; i < n; i++) {
+      const gm_diag_result_t& r = res[i];
+      std::string msg;
+      for (const char* c = r.message; *c; c++) {
+        if (*c == '"' || *c == '\\') msg += '\\';
+        msg += (unsigned char)*c < 0x20 ? ' ' : *c;
+      }
+      s += std::string(i ? "," : "") + "{\"test\":\"" + r.test + "\",\"system\":\"" + health_system_name(r.system) + "\",\"health\":\"" +
+           health_result_name(r.health) + "\",\"value\":" + (std::isnan(r.value) ? std::string("null") : strprintf("%.6g", r.value)) +
+           ",\"time\":\"" + format_time_us(r.ts_us) + "\",\"message\":\"" + msg + "\"}";
+    }
+    s += "]}\n";
+  } else {
+    s = strprintf("Diagnostics of GPU %u\n%-14s %-10s %-9s %12s  %-24s %s\n", gpu, "Test", "System", "Result", "Value", "When", "Message");
+    for (int i = 0; i < n; i++) {
+      const gm_diag_result_t& r = res[i];
+      s += strprintf("%-14s %-10s %-9s %12s  %-24s %s\n", r.test, health_system_name(r.system), health_result_name(r.health),
+                     std::isnan(r.value) ? "N/A" : strprintf("%.6g", r.value).c_str(), format_time_us(r.ts_us).c_str(), r.message);
+    }
+    if (!n) s += "(no diagnostic has reported)\n";
+  }
+  *out = s;
+  return GM_ST_OK;
+}
+
 std::string view_violation(const gm_violation_t& v) {
   std::string s = strprintf("GPU %u: %s at %s: ", v.gpu, policy_condition_name(v.condition), format_time_us(v.ts_us).c_str());
   switch (v.condition) {

@@ -1057,14 +1057,26 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 }
 
 // ---- output checksum (integer, order-independent -> bitwise reproducible) ----
-__global__ void checksum_kernel(const uint4* __restrict__ c, uint64_t n16, unsigned long long* out) {
+using csum_u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ unsigned long long checksum_word(csum_u32x4 v) {
+  return (unsigned long long)v.x * 0x9E3779B1u + (unsigned long long)v.y * 0x85EBCA77u + (unsigned long long)v.z * 0xC2B2AE3Du +
+         (unsigned long long)v.w * 0x27D4EB2Fu;
+}
+
+// Runs between the launches of a soak, so it is written to take HBM time and no more: four independent streaming
+// 16-byte loads in flight per lane (C was stored non-temporally and comes from memory, not from a cache).
+__global__ __launch_bounds__(256) void checksum_kernel(const uint4* __restrict__ c4, uint64_t n16, unsigned long long* out) {
+  const csum_u32x4* c = reinterpret_cast<const csum_u32x4*>(c4);
   unsigned long long s = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-    uint4 v = c[i];
-    s += (unsigned long long)v.x * 0x9E3779B1u + (unsigned long long)v.y * 0x85EBCA77u +
-         (unsigned long long)v.z * 0xC2B2AE3Du + (unsigned long long)v.w * 0x27D4EB2Fu;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const csum_u32x4 v0 = __builtin_nontemporal_load(c + i), v1 = __builtin_nontemporal_load(c + i + stride);
+    const csum_u32x4 v2 = __builtin_nontemporal_load(c + i + 2 * stride), v3 = __builtin_nontemporal_load(c + i + 3 * stride);
+    s += checksum_word(v0) + checksum_word(v1) + checksum_word(v2) + checksum_word(v3);
   }
+  for (; i < n16; i += stride) s += checksum_word(__builtin_nontemporal_load(c + i));
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
@@ -1549,7 +1561,7 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
     GMD_HIP(hipEventRecord(e0, 0));
     for (int i = 0; i < batch; i++) {
       if ((rc = launch())) return rc;
-      if (verify) checksum_kernel<<<1024, 256>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + in_window + i);
+      if (verify) checksum_kernel<<<2048, 256>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + in_window + i);
     }
     GMD_HIP(hipEventRecord(e1, 0));
     GMD_HIP(hipEventSynchronize(e1));

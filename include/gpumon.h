@@ -790,7 +790,9 @@ typedef enum {
   GM_VIEW_HEALTH = 2,
   GM_VIEW_PROCESS = 3,     /* id = pid */
   GM_VIEW_HOSTENGINE = 4,  /* id ignored */
-  GM_VIEW_TOPOLOGY = 5     /* id ignored; text only */
+  GM_VIEW_TOPOLOGY = 5,    /* id ignored; text only */
+  GM_VIEW_LINKS = 6,       /* id = gpu: per-link xGMI table */
+  GM_VIEW_DIAG = 7         /* id = gpu: latest verdict of every active diagnostic */
 } gm_view_t;
 GM_API gm_status_t gm_render_view(int view, uint32_t id, int json, char* out, size_t* len);
 GM_API gm_status_t gm_format_violation(const gm_violation_t* v, char* out, size_t* len);

@@ -457,7 +457,7 @@ class Exporter:
 
 
 def render_view(view, ident=0, json=False):
-    views = {"device_info": 0, "device_status": 1, "health": 2, "process": 3, "hostengine": 4, "topology": 5}
+    views = {"device_info": 0, "device_status": 1, "health": 2, "process": 3, "hostengine": 4, "topology": 5, "links": 6, "diag": 7}
     cap = 1 << 16
     while True:
         buf = C.create_string_buffer(cap)

@@ -249,6 +249,53 @@ def test_link_test_report_carries_one_verdict_per_gpu(engine, tmp_path):
     assert res[1]["status"] == "Failure" and res[0]["status"] == "Healthy"
 
 
+def test_links_and_diagnostics_views_cli_and_rest(engine, tmp_path):
+    """`gpumon links`, `gpumon diag`, and the REST routes /gpumon/links/id/N and /gpumon/diag/id/N (text and /json)."""
+    import signal
+    import socket
+    import urllib.request
+    text = E.render_view("links", 2)
+    assert text.splitlines()[0] == "xGMI links of GPU 2" and len(text.splitlines()) == 2 + 7
+    assert "Up" in text and "0000:" in text
+    doc = json.loads(E.render_view("links", 2, json=True))
+    assert doc["gpu"] == 2 and [l["peer_gpu"] for l in doc["links"]] == [0, 1, 3, 4, 5, 6, 7]
+    assert all(l["state"] == "up" and l["max_bandwidth_gbps"] == 608 for l in doc["links"])
+    E.diag_result_submit(2, "memtest", H["MEM"], A.HEALTH_FAIL, "3 words differ", value=3.0)
+    d = json.loads(E.render_view("diag", 2, json=True))
+    assert d["results"][0]["test"] == "memtest" and d["results"][0]["health"] == "Failure" and d["results"][0]["value"] == 3
+    assert "memtest" in E.render_view("diag", 2) and "(no diagnostic has reported)" in E.render_view("diag", 5)
+    with pytest.raises(E.GpumonError):
+        E.render_view("links", 99)
+
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=4,seed=1,steady=1")
+    r = subprocess.run([bin_path("gpumon"), "links", "-g", "1", "--json"], env=env, capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and [l["peer_gpu"] for l in json.loads(r.stdout)["links"]] == [0, 2, 3]
+    r = subprocess.run([bin_path("gpumon"), "diag"], env=env, capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and r.stdout.count("Diagnostics of GPU") == 4
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    sock = str(tmp_path / "he.sock")
+    p = subprocess.Popen([bin_path("gpumon-hostengine"), "--domain-socket", sock, "--http", f"127.0.0.1:{port}", "--pid-file",
+                          str(tmp_path / "he.pid")], env=env, stderr=subprocess.PIPE)
+    try:
+        for _ in range(100):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        get = lambda path: urllib.request.urlopen(f"http://127.0.0.1:{port}{path}", timeout=5).read().decode()  # noqa: E731
+        assert [l["peer_gpu"] for l in json.loads(get("/gpumon/links/id/3/json"))["links"]] == [0, 1, 2]
+        assert get("/gpumon/links/id/0").startswith("xGMI links of GPU 0")
+        assert json.loads(get("/gpumon/diag/id/0/json")) == {"gpu": 0, "results": []}
+        with pytest.raises(urllib.error.HTTPError):
+            get("/gpumon/links/id/9")
+    finally:
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=10)
+
+
 # ------------------------------------------------------------ link grading --
 def _matrix(n, value, **cells):
     m = [[0.0 if i == j else float(value) for j in range(n)] for i in range(n)]
