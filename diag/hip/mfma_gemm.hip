@@ -866,7 +866,9 @@ __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x
 }
 #define W4_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
-template <int DT, int ABL = 0, int EPI = 1>  // ABL 16: clock stamps (ablation builds only); EPI: see store_acc
+// ABL (ablation builds only; results are wrong, timing is the point): 1 no fragment reads, 2 no DMA, 4 no MFMAs,
+// 16 clock stamps, 32 no barriers.  EPI: see store_acc.
+template <int DT, int ABL = 0, int EPI = 1>
 __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                              __bf16* __restrict__ C, int M, int N, size_t row_bytes,
                                                              const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB) {
@@ -911,9 +913,25 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     asm volatile("" : "+s"(base));
     return base;
   };
-  auto dma = [&](const char* base, int slot, int i) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
-                                     (__attribute__((address_space(3))) void*)(my_pieces + slot * kHalfBytes + i * 1024), 16, 0, 0);
+  // One LDS-DMA instruction per piece and nothing else: the source is SGPR base + 32-bit VGPR offset + immediate, the
+  // LDS side M0 + the SAME immediate, so the four pieces of a half-tile share one M0 write (piece i's VGPR offset has
+  // i KiB taken off to make up for the immediate on the global side).  Through the builtin every piece costs a 64-bit
+  // VALU add and an M0 write of its own, and with one wave per SIMD a VALU instruction is an MFMA issue slot lost
+  // (measured: 12 k of 293 k cycles per tile).
+  uint32_t off_imm[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) off_imm[i] = off[i] - (uint32_t)(i * 1024);
+  auto dma = [my_pieces, o0 = off_imm[0], o1 = off_imm[1], o2 = off_imm[2], o3 = off_imm[3]](const char* base, int slot, auto I) {
+    constexpr int i = decltype(I)::value;
+    const uint32_t lds = (uint32_t)(uintptr_t)(my_pieces + slot * kHalfBytes);
+    const uint32_t o = i == 0 ? o0 : i == 1 ? o1 : i == 2 ? o2 : o3;
+    // Every statement names M0 as clobbered: pieces 1..3 rely on the M0 that piece 0 wrote, and the clobber is what
+    // keeps the compiler from parking an M0 write of its own between them.
+    if constexpr (i == 0)
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(0), "s"(lds)
+                   : "memory", "m0");
+    else
+      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(i * 1024) : "memory", "m0");
   };
   // MX scales: the packed unit (256 B: 64 rows x 4 blocks of one K-tile) that belongs to a half-tile travels with
   // it, by one 4-byte-per-lane LDS-DMA into this wave's own slot of a small ring behind the operand ring.
@@ -922,13 +940,15 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   const uint32_t* sc_a = nullptr;
   const uint32_t* sc_b = nullptr;
   if constexpr (kMx) {
-    sc_a = SA + (size_t)(4 * tm + 2 * wr) * ktiles * kScaleUnitDwords + lane;
-    sc_b = SB + (size_t)(4 * tn + 2 * wc) * ktiles * kScaleUnitDwords + lane;
+    sc_a = SA + (size_t)(4 * tm + 2 * wr) * ktiles * kScaleUnitDwords;  // wave-uniform; the lane's dword is the VGPR offset
+    sc_b = SB + (size_t)(4 * tn + 2 * wc) * ktiles * kScaleUnitDwords;
   }
+  const uint32_t lane4 = (uint32_t)lane * 4;
   auto dma_scale = [&](int kind, int kt, int slot) {
     const uint32_t* src = ((kind == 0 || kind == 3) ? sc_a : sc_b) + ((size_t)(kind >= 2 ? ktiles : 0) + kt) * kScaleUnitDwords;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(my_scales + slot * 256), 4, 0, 0);
+    const uint32_t lds = (uint32_t)(uintptr_t)(my_scales + slot * 256);
+    const uint32_t* lane_src = src + lane;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(lane_src), "s"(lds) : "memory", "m0");
   };
   auto read_scale = [&](int slot) { return *(const int*)(my_scales + slot * 256 + lane * 4); };
 
@@ -960,8 +980,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const char* base = piece_base(j & 3, j >> 2);
-#pragma unroll
-    for (int i = 0; i < 4; i++) dma(base, j, i);
+    dma(base, j, std::integral_constant<int, 0>{});
+    dma(base, j, std::integral_constant<int, 1>{});
+    dma(base, j, std::integral_constant<int, 2>{});
+    dma(base, j, std::integral_constant<int, 3>{});
     if constexpr (kMx) dma_scale(j & 3, j >> 2, j);
   }
   wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
@@ -1003,11 +1025,21 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 #pragma unroll
     for (int i = 0; i < NM; i++) {
       const int sub = i >> 4, mb = (i >> 2) & 3, nb = i & 3;
-      mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], sub, mb, nb, sAf, sBf);
-      if (i < 8) read_one(Rf, rslot, rk == 0 || rk == 3, i);
-      else if (i < 12) dma(base, P, i - 8);
-      else if (kMx && i == 12) dma_scale(p, ikt, P);
-      else if (kMx && i == 13) sRf = read_scale(rslot);
+      if constexpr (!(ABL & 4)) mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], sub, mb, nb, sAf, sBf);
+      if (i < 8) {
+        if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i);
+      } else if (i < 12) {
+        if constexpr (!(ABL & 2)) {
+          if (i == 8) dma(base, P, std::integral_constant<int, 0>{});
+          else if (i == 9) dma(base, P, std::integral_constant<int, 1>{});
+          else if (i == 10) dma(base, P, std::integral_constant<int, 2>{});
+          else dma(base, P, std::integral_constant<int, 3>{});
+        }
+      } else if (kMx && i == 12) {
+        if constexpr (!(ABL & 2)) dma_scale(p, ikt, P);
+      } else if (kMx && i == 13) {
+        if constexpr (!(ABL & 1)) sRf = read_scale(rslot);
+      }
       if (i < (kMx ? 14 : 12)) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (kMx) asm volatile("" ::"v"(sAf), "v"(sBf));
@@ -1021,7 +1053,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     if constexpr (P & 1) {
       wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      GMD_PHASE_FENCE();
+      if constexpr (!(ABL & 32)) GMD_PHASE_FENCE();
     } else {
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1363,7 +1395,19 @@ int launch_gemm_t(const GemmArgs& g) {
       default: break;
     }
   }
-  if (gemm_variant() == 51) return launch_lds(gemm_w4_kernel<DT, 16>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
+  {
+    const int w4_lds = kLdsBytes + (kMx ? kScaleRingBytes : 0);
+    switch (gemm_variant()) {
+      case 51: return launch_lds(gemm_w4_kernel<DT, 16>, grid, kThreadsW4, w4_lds, g);
+      case 62: return launch_lds(gemm_w4_kernel<DT, 16 | 3>, grid, kThreadsW4, w4_lds, g);   // MFMAs + barriers
+      case 63: return launch_lds(gemm_w4_kernel<DT, 16 | 1>, grid, kThreadsW4, w4_lds, g);   // no fragment reads
+      case 64: return launch_lds(gemm_w4_kernel<DT, 16 | 2>, grid, kThreadsW4, w4_lds, g);   // no DMA
+      case 65: return launch_lds(gemm_w4_kernel<DT, 16 | 5>, grid, kThreadsW4, w4_lds, g);   // DMA only
+      case 66: return launch_lds(gemm_w4_kernel<DT, 16 | 32>, grid, kThreadsW4, w4_lds, g);  // no barriers
+      case 67: return launch_lds(gemm_w4_kernel<DT, 16 | 3 | 32>, grid, kThreadsW4, w4_lds, g);  // MFMAs alone
+      default: break;
+    }
+  }
 #endif
   // auto: bf16 and fp8 run the eight-wave kernels (the stream when there are more tiles than CUs), MX-fp8 the
   // four-wave one, which is also the only pipeline that carries scales.
@@ -1393,7 +1437,7 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53) {
+      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 67)) {
     g_gemm_variant = variant;
     return GMD_OK;
   }
