@@ -1218,12 +1218,13 @@ class AmdSmiBackend : public Backend {
       memset(&ec, 0, sizeof ec);
       rc = api_.amdsmi_get_gpu_total_ecc_count(d.h, &ec);
       if (rc == AMDSMI_STATUS_SUCCESS) {
-        // The driver keeps one set of counters (since load); the persistent view
-        // is the same numbers until the RAS EEPROM totals are exposed.
+        // The driver keeps one set of counters, since it was loaded: that is the volatile pair.  The lifetime totals
+        // (RAS EEPROM) are not exposed by the device library, so the aggregate pair is blank rather than a second
+        // copy of the same numbers under another name.
         out->set_i(GM_FI_ECC_CE_VOLATILE, (int64_t)ec.correctable_count);
         out->set_i(GM_FI_ECC_UE_VOLATILE, (int64_t)ec.uncorrectable_count);
-        out->set_i(GM_FI_ECC_CE_AGGREGATE, (int64_t)ec.correctable_count);
-        out->set_i(GM_FI_ECC_UE_AGGREGATE, (int64_t)ec.uncorrectable_count);
+        out->set_blank(GM_FI_ECC_CE_AGGREGATE, GM_VS_NOT_SUPPORTED);
+        out->set_blank(GM_FI_ECC_UE_AGGREGATE, GM_VS_NOT_SUPPORTED);
         out->set_i(GM_FI_ECC_DEFERRED, (int64_t)ec.deferred_count);
         ok = true;
       }
@@ -1289,9 +1290,9 @@ class AmdSmiBackend : public Backend {
     for (uint32_t i = 0; i < n && i < recs.size(); i++) {
       if (recs[i].status == AMDSMI_MEM_PAGE_STATUS_PENDING) pending++; else reserved++;
     }
-    // The driver retires pages for uncorrectable errors (and correctable storms
-    // it escalates); it does not say which, so all retired pages count as UE.
-    out->set_i(GM_FI_BAD_PAGES_CE, 0);
+    // The driver retires pages for uncorrectable errors (and correctable storms it escalates); the record does not
+    // say which, so every retired page counts as UE and the correctable-cause count is blank, not a made-up 0.
+    out->set_blank(GM_FI_BAD_PAGES_CE, GM_VS_NOT_SUPPORTED);
     out->set_i(GM_FI_BAD_PAGES_UE, reserved);
     out->set_i(GM_FI_BAD_PAGES_PENDING, pending);
     return true;

@@ -1062,7 +1062,7 @@ gm_status_t LocalEngine::fake_ctl(const std::string& cmd) { return backend_->con
 const uint16_t kStatusFields[] = {
     GM_FI_POWER_USAGE, GM_FI_GPU_TEMP, GM_FI_GFX_UTIL, GM_FI_MEM_UTIL, GM_FI_ENC_UTIL, GM_FI_DEC_UTIL,
     GM_FI_GFX_CLOCK, GM_FI_MEM_CLOCK, GM_FI_DEV_VIS_VRAM_USED, GM_FI_PCIE_RX_KB, GM_FI_PCIE_TX_KB,
-    GM_FI_PCIE_REPLAY_COUNTER, GM_FI_VRAM_USED, GM_FI_VRAM_FREE, GM_FI_ECC_CE_AGGREGATE, GM_FI_ECC_UE_AGGREGATE,
+    GM_FI_PCIE_REPLAY_COUNTER, GM_FI_VRAM_USED, GM_FI_VRAM_FREE, GM_FI_ECC_CE_VOLATILE, GM_FI_ECC_UE_VOLATILE,
     GM_FI_PERF_LEVEL, GM_FI_FAN_SPEED, GM_FI_THROTTLE_STATUS, GM_FI_MEM_TEMP, GM_FI_TOTAL_ENERGY};
 const int kNumStatusFields = (int)(sizeof kStatusFields / sizeof kStatusFields[0]);
 
