@@ -59,7 +59,7 @@ struct Args {
 const char* kFlagsWithValue[] = {"-g", "--bytes", "--iters", "--kernel", "--min-tbps", "--fraction", "--patterns", "--passes",
                                  "--dtype", "--seconds", "--m", "--n", "--k", "--gpus", "--ops", "--min-bytes",
                                  "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor", "--publish", "--modes", "--floor-gbps",
-                                 "--warn-ratio", "--fail-ratio", "--workgroups"};
+                                 "--warn-ratio", "--fail-ratio", "--workgroups", "--submit", "--min-busbw"};
 
 bool parse(const std::vector<std::string>& in, Args* a) {
   for (size_t i = 0; i < in.size(); i++) {

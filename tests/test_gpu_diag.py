@@ -428,3 +428,49 @@ def test_torch_distributed_sweep_on_rccl(dev):
         assert {p.op for p in pts} == set(C.OPS) and all(p.verified for p in pts)
     finally:
         dist.destroy_process_group()
+
+
+def test_failed_diagnostic_reaches_a_running_host_engine_and_a_pass_clears_it(tmp_path):
+    """gpumon-diag --submit against a real gpumon-hostengine on the device library: a stream test held to an
+    impossible floor becomes a Memory health failure and a DIAG_FAIL event of THAT GPU (matched by PCI address);
+    the same test with a sane floor replaces it."""
+    import os
+    import signal
+    import subprocess
+    import time
+    from conftest import bin_path
+    from k8s_gpu_monitor_amd import abi as A
+    from k8s_gpu_monitor_amd import engine as E
+    sock = str(tmp_path / "he.sock")
+    he = subprocess.Popen([bin_path("gpumon-hostengine"), "--domain-socket", sock, "--pid-file", str(tmp_path / "he.pid")],
+                          env=dict(os.environ, GPUMON_BACKEND="amdsmi"), stderr=subprocess.PIPE)
+    try:
+        for _ in range(200):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        assert os.path.exists(sock), "host engine did not come up"
+        diag = [bin_path("gpumon-diag"), "hbm", "--bytes", "1G", "--iters", "3", "--kernel", "copy", "--submit", sock, "--submit-unix"]
+        r = subprocess.run(diag + ["--min-tbps", "99"], capture_output=True, text=True, timeout=100)
+        assert r.returncode == 1, r.stdout + r.stderr
+        E.init(mode=E.STANDALONE, address=sock, is_unix_socket=True)
+        try:
+            from k8s_gpu_monitor_amd.ops import diag as D
+            bdf = D.device_info(0)["pci_bdf"].lower()
+            gpu = next(i for i in range(E.device_count()) if E.device_attributes(i)["pci_bdf"].lower() == bdf)
+            res = {d["test"]: d for d in E.diag_results(gpu)}
+            assert res["hbm_stream"]["health"] == A.HEALTH_FAIL and "99" in res["hbm_stream"]["message"], res
+            g = E.group_create("diag-hil", [gpu])
+            E.health_set(g, A.HEALTH["MEM"])
+            h = E.health_check(g)[0]
+            assert h["status"] == "Failure" and any("hbm_stream" in w["error"] or "TB/s" in w["error"] for w in h["watches"]), h
+            r = subprocess.run(diag + ["--min-tbps", "3"], capture_output=True, text=True, timeout=100)
+            assert r.returncode == 0, r.stdout + r.stderr
+            res = {d["test"]: d for d in E.diag_results(gpu)}
+            assert res["hbm_stream"]["health"] == A.HEALTH_PASS, res
+            assert E.health_check(g)[0]["status"] == "Healthy"
+        finally:
+            E.shutdown()
+    finally:
+        he.send_signal(signal.SIGTERM)
+        he.wait(timeout=15)

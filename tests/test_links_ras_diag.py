@@ -367,3 +367,16 @@ def test_link_test_without_a_gpu_is_an_error_not_a_crash():
         pytest.skip("a GPU is present")
     with pytest.raises(diag.DiagError):
         diag.link_test("uni", devices=[0])
+
+
+def test_gpumon_diag_takes_every_documented_value_flag():
+    """Every flag of the usage text that carries a value is parsed as such (a flag missing from the parser's list
+    turns its value into an 'unexpected argument').  Without a GPU the commands then stop at the device, not at
+    the command line."""
+    import re
+    usage = subprocess.run([bin_path("gpumon-diag")], capture_output=True, text=True).stderr
+    flags = set(re.findall(r"(--?[a-z][a-z-]*) [A-Z_|0-9a-z]*[A-Z]", usage))
+    assert {"--submit", "--min-busbw", "--floor-gbps", "--publish", "--bytes", "-g"} <= flags, sorted(flags)
+    for f in sorted(flags):
+        r = subprocess.run([bin_path("gpumon-diag"), "links", f, "7"], capture_output=True, text=True, timeout=60)
+        assert "unexpected argument" not in r.stderr and "missing value" not in r.stderr, (f, r.stderr)
