@@ -1026,21 +1026,46 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     for (int i = 0; i < NM; i++) {
       const int sub = i >> 4, mb = (i >> 2) & 3, nb = i & 3;
       if constexpr (!(ABL & 4)) mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], sub, mb, nb, sAf, sBf);
-      if (i < 8) {
-        if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i);
-      } else if (i < 12) {
-        if constexpr (!(ABL & 2)) {
-          if (i == 8) dma(base, P, std::integral_constant<int, 0>{});
-          else if (i == 9) dma(base, P, std::integral_constant<int, 1>{});
-          else if (i == 10) dma(base, P, std::integral_constant<int, 2>{});
-          else dma(base, P, std::integral_constant<int, 3>{});
+      if constexpr (kMx) {
+        // sixteen MFMAs per phase: reads behind the first eight, then the four pieces, the scale unit, the scale read
+        if (i < 8) {
+          if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i);
+        } else if (i < 12) {
+          if constexpr (!(ABL & 2)) {
+            if (i == 8) dma(base, P, std::integral_constant<int, 0>{});
+            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{});
+            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{});
+            else dma(base, P, std::integral_constant<int, 3>{});
+          }
+        } else if (i == 12) {
+          if constexpr (!(ABL & 2)) dma_scale(p, ikt, P);
+        } else if (i == 13) {
+          if constexpr (!(ABL & 1)) sRf = read_scale(rslot);
         }
-      } else if (kMx && i == 12) {
-        if constexpr (!(ABL & 2)) dma_scale(p, ikt, P);
-      } else if (kMx && i == 13) {
-        if constexpr (!(ABL & 1)) sRf = read_scale(rslot);
+        if (i < 14) __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // 32 (bf16) or 64 (fp8) MFMAs per phase: fragment read j behind MFMA j*kReadStep, DMA piece q behind MFMA
+        // kDma0 + q*kDmaStep.  With one wave per SIMD a memory instruction right behind another one costs MFMA issue
+        // slots; pieces two MFMAs apart measured 1.6 % fewer cycles per tile than back to back.
+        constexpr int SCHED = ABL >> 8;
+        constexpr int kReadStep = (SCHED == 2 || SCHED == 4) ? 2 : 1;
+        constexpr int kDma0 = SCHED == 0 ? 8 : SCHED == 1 ? 8 : SCHED == 2 ? 17 : SCHED == 3 ? 12 : 16;
+        constexpr int kDmaStep = SCHED == 0 ? 2 : SCHED == 1 ? 1 : SCHED == 2 ? 4 : SCHED == 3 ? 5 : 3;
+        static_assert(7 * kReadStep < NM && kDma0 + 3 * kDmaStep < NM, "schedule does not fit the phase");
+        if (i % kReadStep == 0 && i / kReadStep < 8) {
+          if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i / kReadStep);
+        }
+        if (i >= kDma0 && (i - kDma0) % kDmaStep == 0 && (i - kDma0) / kDmaStep < 4) {
+          if constexpr (!(ABL & 2)) {
+            const int q = (i - kDma0) / kDmaStep;
+            if (q == 0) dma(base, P, std::integral_constant<int, 0>{});
+            else if (q == 1) dma(base, P, std::integral_constant<int, 1>{});
+            else if (q == 2) dma(base, P, std::integral_constant<int, 2>{});
+            else dma(base, P, std::integral_constant<int, 3>{});
+          }
+        }
+        if (i <= (kDma0 + 3 * kDmaStep > 7 * kReadStep ? kDma0 + 3 * kDmaStep : 7 * kReadStep)) __builtin_amdgcn_sched_barrier(0);
       }
-      if (i < (kMx ? 14 : 12)) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (kMx) asm volatile("" ::"v"(sAf), "v"(sBf));
     // Keep both operand sets whole until the phase's last MFMA, so that no half of them is handed to one of
@@ -1405,14 +1430,20 @@ int launch_gemm_t(const GemmArgs& g) {
       case 65: return launch_lds(gemm_w4_kernel<DT, 16 | 5>, grid, kThreadsW4, w4_lds, g);   // DMA only
       case 66: return launch_lds(gemm_w4_kernel<DT, 16 | 32>, grid, kThreadsW4, w4_lds, g);  // no barriers
       case 67: return launch_lds(gemm_w4_kernel<DT, 16 | 3 | 32>, grid, kThreadsW4, w4_lds, g);  // MFMAs alone
+      case 68: return launch_lds(gemm_w4_kernel<DT, 16 | (1 << 8)>, grid, kThreadsW4, w4_lds, g);  // pieces back to back (old)
+      case 69: return launch_lds(gemm_w4_kernel<DT, 16 | (2 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 4 apart
+      case 70: return launch_lds(gemm_w4_kernel<DT, 16 | (3 << 8)>, grid, kThreadsW4, w4_lds, g);  // pieces 5 apart from 12
+      case 71: return launch_lds(gemm_w4_kernel<DT, 16 | (4 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 3 apart
       default: break;
     }
   }
 #endif
-  // auto: bf16 and fp8 run the eight-wave kernels (the stream when there are more tiles than CUs), MX-fp8 the
-  // four-wave one, which is also the only pipeline that carries scales.
+  // auto, by measurement (scripts/gpu_gemm_ab.py): MX-fp8 runs the four-wave kernel, the only pipeline that carries
+  // scales; unscaled fp8 runs it too (1-2 % ahead of the eight-wave kernels at 4096..16384); bf16 runs it up to four
+  // tiles per CU (0.5-2 % ahead at 4096 and 8192) and the eight-wave stream beyond (0.7 % ahead at 16384).
   int variant = gemm_variant();
-  if (variant < 0 || variant > kVariantMax) variant = kMx ? 2 : 3;
+  if (variant < 0 || variant > kVariantMax)
+    variant = (kMx || DT == GMD_DT_FP8) ? 2 : (size_t)grid <= 4 * (size_t)persistent_grid() ? 2 : 3;
   if (kMx && variant != 0) variant = 2;
   if (!pairs) variant = 0;
   if (variant == 3 && !stream_ok) variant = 1;
@@ -1437,7 +1468,7 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 67)) {
+      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 71)) {
     g_gemm_variant = variant;
     return GMD_OK;
   }

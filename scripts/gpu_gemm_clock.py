@@ -25,7 +25,8 @@ stream = torch.cuda.current_stream().cuda_stream
 SOAK_S = float(os.environ.get("SOAK_S", "2.0"))
 ARMS = {41: "full", 42: "mfma + barriers", 43: "no reads", 44: "no dma", 45: "dma only", 46: "full, operands L2-resident",
         51: "four waves x 128x128", 62: "four waves: mfma + barriers", 63: "four waves: no reads", 64: "four waves: no dma",
-        65: "four waves: dma only", 66: "four waves: no barriers", 67: "four waves: mfma alone"}
+        65: "four waves: dma only", 66: "four waves: no barriers", 67: "four waves: mfma alone", 68: "four waves: pieces back to back", 69: "four waves: reads 2 apart, pieces 4 apart",
+        70: "four waves: pieces 5 apart", 71: "four waves: reads 2 apart, pieces 3 apart"}
 if os.environ.get("GEMM_CLOCK_ONLY"):
     ARMS = {int(v): ARMS[int(v)] for v in os.environ["GEMM_CLOCK_ONLY"].split(",")}
 out = []
