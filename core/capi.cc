@@ -163,6 +163,13 @@ gm_status_t do_init(Global& g, const gm_init_params_t* p) {
     // posix_spawn, not fork: the caller is an arbitrary, usually multithreaded host (Python with a GPU runtime, a Go
     // program), and a forked copy of such a process must not run anything but exec.  Own process group: terminal
     // signals to the parent do not reach the daemon.
+    for (const char* hip : {"libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"})
+      if (void* h = dlopen(hip, RTLD_LAZY | RTLD_NOLOAD)) {
+        dlclose(h);
+        // Worth a line in the log: on hosts that forbid replacing a GPU-initialised program this is the call to look at.
+        GM_LOGW("starting gpumon-hostengine from a process that has the HIP runtime loaded (posix_spawn: no copy of this process runs)");
+        break;
+      }
     std::vector<std::string> args = {bin, "--domain-socket", address, "--backend", backend};
     if (!spec.empty()) {
       args.push_back("--backend-spec");
