@@ -3,6 +3,7 @@
 // the sampler <-> reader hand-off, concurrent control-plane calls, the RPC
 // server with several clients, and the text parsers on hostile input.
 // Plain asserts; no test framework.
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -17,6 +18,7 @@
 #include "core/common/util.h"
 #include "core/exporter/exporter.h"
 #include "core/fields.h"
+#include "core/prof/prof_child.h"
 #include "core/rpc/server.h"
 #include "gpumon.h"
 
@@ -336,6 +338,75 @@ static void test_parsers() {
   printf("parsers ok\n");
 }
 
+// -- counter windows from a probe child ---------------------------------------------
+static void test_prof_child() {
+  std::string pci;
+  ProfWindow w;
+  CHECK(parse_probe_line("sample pci=0000:5D:00.0 window_s=0.750 gpu_active=99.1 cu_active=nan mem_pipe_active=61 mfma_active=84.25 clock_mhz=1934", &pci, &w));
+  CHECK(pci == "0000:5d:00.0" && w.window_s == 0.75 && w.gpu_active == 99.1 && std::isnan(w.cu_active) && w.mfma_active == 84.25 && w.clock_mhz == 1934);
+  CHECK(parse_probe_line("sample pci=0000:05:00.0 mfma_active=140 gpu_active=-3", &pci, &w) && std::isnan(w.mfma_active) && std::isnan(w.gpu_active));
+  CHECK(!parse_probe_line("agents: 1", &pci, &w) && !parse_probe_line("sample window_s=1", &pci, &w) && !parse_probe_line("", &pci, &w));
+  std::mt19937 rng(5);
+  const char al[] = "sample pci=:.0123456789abcdefnan_ =\n\x01\xff";
+  for (int i = 0; i < 20000; i++) {
+    std::string s = rng() % 2 ? "sample " : "";
+    int len = rng() % 80;
+    for (int k = 0; k < len; k++) s += al[rng() % (sizeof al - 1)];
+    parse_probe_line(s.c_str(), &pci, &w);  // must not crash
+  }
+
+  char dir[] = "/tmp/gpumon-probe-XXXXXX";
+  CHECK(mkdtemp(dir));
+  auto script = [&](const char* name, const char* body) {
+    std::string path = std::string(dir) + "/" + name;
+    FILE* f = fopen(path.c_str(), "w");
+    CHECK(f);
+    fprintf(f, "#!/bin/sh\n%s", body);
+    fclose(f);
+    chmod(path.c_str(), 0755);
+    return path;
+  };
+  {
+    ProfChildSampler s(script("ok.sh", "echo 'agents: 2'\necho 'sample pci=0000:05:00.0 window_s=0.3 gpu_active=50 cu_active=40 mem_pipe_active=30 mfma_active=20 clock_mhz=2000'\n"), 1.0, 50);
+    s.start();
+    for (int i = 0; i < 100 && !s.latest("0000:05:00.0", &w); i++) usleep(20000);
+    CHECK(s.latest("0000:05:00.0", &w) && w.mfma_active == 20 && w.cu_active == 40);
+    CHECK(s.latest("0000:05:00.0", &w) && w.taken_mono_us > 0);
+    CHECK(!s.latest("0000:15:00.0", &w));  // a GPU the probe did not report
+    CHECK(s.runs() >= 1 && s.failures() == 0);
+    // readers from several threads while the loop keeps replacing the window
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> readers;
+    for (int t = 0; t < 3; t++)
+      readers.emplace_back([&] {
+        ProfWindow x;
+        while (!stop) s.latest("0000:05:00.0", &x);
+      });
+    usleep(1300000);
+    stop = true;
+    for (auto& t : readers) t.join();
+    CHECK(s.runs() >= 2);
+  }
+  {
+    ProfChildSampler s(script("fail.sh", "echo 'gmp_open: no device' >&2\nexit 1\n"), 1.0, 50);
+    s.start();
+    for (int i = 0; i < 100 && s.runs() == 0; i++) usleep(20000);
+    CHECK(s.runs() >= 1 && s.failures() >= 1 && !s.latest("0000:05:00.0", &w));
+  }
+  {
+    // a probe that never ends: destroying the sampler ends it (the exact child) and returns promptly
+    ProfChildSampler s(script("hang.sh", "exec sleep 300\n"), 1.0, 50);
+    s.start();
+    usleep(200000);
+    const int64_t t0 = monotonic_us();
+    (void)t0;
+  }
+  { ProfChildSampler s(std::string(dir) + "/missing", 1.0, 50); s.start(); usleep(100000); CHECK(s.failures() >= 1); }
+  std::string cmd = std::string("rm -rf ") + dir;
+  CHECK(system(cmd.c_str()) == 0);
+  printf("prof child ok\n");
+}
+
 // -- refcount + direct layer ------------------------------------------------------
 static void test_lifecycles() {
   CHECK(gm_shutdown() == GM_ST_UNINITIALIZED);
@@ -378,6 +449,7 @@ int main() {
   test_registry();
   OK(gm_shutdown());
   test_parsers();
+  test_prof_child();
   test_concurrent_engine();
   test_rpc();
   printf("ALL OK\n");
