@@ -133,7 +133,7 @@ void ProfChildSampler::loop() {
     // After three failures in a row the child is tried once a minute only: a host without the counters must not
     // pay for a start-up every period.
     const double wait_s = (!ok && failures_.load() >= 3 && failures_.load() == runs_.load()) ? std::max(60.0, period_s_) : period_s_;
-    if (cv_.wait_for(l, std::chrono::duration<double>(wait_s), [this] { return stop_; })) return;
+    if (cv_wait_for(cv_, l, std::chrono::microseconds((int64_t)(wait_s * 1e6)), [this] { return stop_; })) return;
   }
 }
 

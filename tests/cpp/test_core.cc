@@ -200,6 +200,37 @@ static void test_concurrent_engine() {
       OK(gm_group_destroy(g2));
     }
   });
+  th.emplace_back([&] {  // diagnostics verdicts, link tables and health levels next to health checks and the sampler
+    int k = 0;
+    while (!stop) {
+      gm_diag_result_t d;
+      memset(&d, 0, sizeof d);
+      d.version = GM_DIAG_RESULT_VERSION;
+      d.gpu = (uint32_t)(k % 8);
+      snprintf(d.test, sizeof d.test, "%s", k % 3 ? "memtest" : "xgmi_p2p");
+      d.system = k % 3 ? GM_HEALTH_WATCH_MEM : GM_HEALTH_WATCH_XGMI;
+      d.health = k % 5 == 0 ? GM_HEALTH_FAIL : k % 5 == 1 ? GM_HEALTH_WARN : GM_HEALTH_PASS;
+      d.value = k;
+      snprintf(d.message, sizeof d.message, "round %d", k);
+      OK(gm_diag_result_submit(&d));
+      gm_diag_result_t got[16];
+      int n = 16;
+      OK(gm_diag_results(d.gpu, got, &n));
+      CHECK(n >= 1 && n <= 2);
+      gm_xgmi_link_t links[GM_MAX_XGMI_LINKS];
+      int nl = GM_MAX_XGMI_LINKS;
+      OK(gm_xgmi_links(d.gpu, links, &nl));
+      CHECK(nl == 7);
+      for (int i = 0; i < nl; i++) CHECK(links[i].peer_gpu >= 0 && links[i].peer_gpu < 8 && (uint32_t)links[i].peer_gpu != d.gpu);
+      gm_health_thresholds_t t;
+      memset(&t, 0, sizeof t);
+      t.version = GM_HEALTH_THRESHOLDS_VERSION;
+      OK(gm_health_thresholds_get(&t));
+      t.hotspot_warn_c = 90 + k % 10;
+      OK(gm_health_thresholds_set(&t));
+      k++;
+    }
+  });
   sleep(2);
   stop = true;
   for (auto& t : th) t.join();
