@@ -168,8 +168,9 @@ GMD_API int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int r
 /* GEMM schedule: -1 = the fastest for the dtype and shape (default); 0 = simple double-buffered loop;
  * 1 = eight waves x 128x64, one workgroup per tile; 2 = four waves x 128x128 with the accumulators in AGPRs;
  * 3 = eight waves x 128x64 as one stream per CU over its tiles (needs more tiles than CUs and >= 4 K-tiles);
- * 4 / 5 = schedule 1 with the narrow / the cached epilogue (A/B references).  The pipelines need an even
- * number of 128-byte K-tiles, otherwise the launch falls back to 0.  MX-fp8 runs 2 (or 0).  All schedules give
+ * 4 / 5 = schedule 1 with the narrow / the cached epilogue (A/B references); 6 = schedule 2 as one stream per
+ * CU (A/B reference, same conditions as 3, otherwise 2 runs).  The pipelines need an even number of 128-byte
+ * K-tiles, otherwise the launch falls back to 0.  MX-fp8 runs 2, 6 or 0.  All schedules give
  * bit-identical results.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
 

@@ -117,7 +117,9 @@ __device__ __forceinline__ void stage(const char* __restrict__ g, size_t row_byt
 // operand <-> even rows of the second), after which every lane holds eight consecutive elements of one block and
 // stores 16 bytes: half the store instructions for the same bytes and addresses.  EPI = 1 also marks the stores
 // non-temporal (C is never read back); EPI = 2 leaves them cached.
-template <int NBLK, int EPI>
+// PACE: one row of blocks at a time (a scheduling fence after each), for callers that hold many live registers
+// across the epilogue: without it the scheduler reads all accumulators first and spills.
+template <int NBLK, int EPI, bool PACE = false>
 __device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* __restrict__ C, size_t ldc, int m0, int nbase,
                                           int fq) {
   if constexpr (EPI == 0) {
@@ -144,6 +146,9 @@ __device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* _
         u32x4* dst = (u32x4*)(C + (size_t)(m0 + mb * 16) * ldc + col + nb * 16);
         if constexpr (EPI == 1) __builtin_nontemporal_store(o, dst);
         else *dst = o;
+        if constexpr (PACE) {
+          if (nb + 2 >= NBLK) __builtin_amdgcn_sched_barrier(0);
+        }
       }
   }
 }
@@ -868,7 +873,13 @@ __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x
 
 // ABL (ablation builds only; results are wrong, timing is the point): 1 no fragment reads, 2 no DMA, 4 no MFMAs,
 // 16 clock stamps, 32 no barriers.  EPI: see store_acc.
-template <int DT, int ABL = 0, int EPI = 1>
+// STREAM: one workgroup per CU walks the tiles j, j + G/8, ... of its XCD's chunk without draining the ring: the
+// half-tiles a tile's last pair issues and reads beyond its end are the first ones of the next tile (they land in
+// the slots and registers that tile's first pair expects), so a tile boundary is the epilogue and nothing else.
+// Measured 1-3 % slower than one workgroup per tile: the one vmcnt counter retires loads, stores and LDS-DMA in order,
+// so the first half-tile issued behind a tile's stores waits for the store burst of all CUs to drain, which the ring
+// covers only in part, while a workgroup that ends after its stores never waits for them.  Kept as an A/B reference.
+template <int DT, int ABL = 0, int EPI = 1, bool STREAM = false>
 __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                              __bf16* __restrict__ C, int M, int N, size_t row_bytes,
                                                              const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB) {
@@ -886,13 +897,34 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   }
 #endif
 
-  const int nwg = gridDim.x;
-  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8n = nwg & 7;
-  const int wgid = (xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8) + (blockIdx.x >> 3);
+  // Per-tile launch: workgroup = tile.  Stream: XCD x owns a contiguous chunk of tiles, its workgroup j walks tiles
+  // j, j + G/8, ... of the chunk.
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  const int nunits = STREAM ? tiles_m * tiles_n : (int)gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = nunits >> 3, r8n = nunits & 7;
+  const int chunk0 = xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8;
+  const int chunk_end = chunk0 + q8 + (xcd < r8n ? 1 : 0);
+  const int tile_step = STREAM ? max((int)gridDim.x >> 3, 1) : 1;
+  int wgid = chunk0 + (int)(blockIdx.x >> 3);
+  if (STREAM && wgid >= chunk_end) return;  // whole workgroup, before any barrier
   int tm, tn;
-  tile_of(wgid, M / BM, N / BN, &tm, &tn);
+  tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
   const char* gA = A + (size_t)tm * BM * row_bytes;
   const char* gB = B + (size_t)tn * BN * row_bytes;
+  // the tile after this one (stream only): where the last pair's surplus half-tiles come from
+  bool has_next = false;
+  int ntm = tm, ntn = tn;
+  const char* nA = gA;
+  const char* nB = gB;
+  auto look_ahead = [&]() {
+    has_next = STREAM && wgid + tile_step < chunk_end;
+    if (has_next) {
+      tile_of(wgid + tile_step, tiles_m, tiles_n, &ntm, &ntn);
+      nA = A + (size_t)ntm * BM * row_bytes;
+      nB = B + (size_t)ntn * BN * row_bytes;
+    }
+  };
+  look_ahead();
 
   // Staging: this wave fills pieces 4*wave .. 4*wave+3 (8 rows x 128 B each) of every slot.  Slot-local row l is
   // tile row (l>>6)*128 + (l&63) [+64 for hi], for A and B alike.
@@ -908,8 +940,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   char* const my_pieces = smem + wave * 4096;
 
   // kind: 0 A-lo, 1 B-lo, 2 B-hi, 3 A-hi.  Wave-uniform part of the source address of one half-tile, kept in SGPRs.
-  auto piece_base = [&](int kind, int kt) {
-    const char* base = ((kind == 0 || kind == 3) ? gA : gB) + ((kind >= 2) ? hi_off : 0) + (size_t)kt * BKB;
+  auto piece_base = [&](int kind, int kt, const char* pa, const char* pb) {
+    const char* base = ((kind == 0 || kind == 3) ? pa : pb) + ((kind >= 2) ? hi_off : 0) + (size_t)kt * BKB;
     asm volatile("" : "+s"(base));
     return base;
   };
@@ -937,15 +969,13 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // it, by one 4-byte-per-lane LDS-DMA into this wave's own slot of a small ring behind the operand ring.
   const int ktiles = (int)(row_bytes / BKB);
   char* const my_scales = smem + kLdsBytes + wave * 8 * 256;
-  const uint32_t* sc_a = nullptr;
-  const uint32_t* sc_b = nullptr;
-  if constexpr (kMx) {
-    sc_a = SA + (size_t)(4 * tm + 2 * wr) * ktiles * kScaleUnitDwords;  // wave-uniform; the lane's dword is the VGPR offset
-    sc_b = SB + (size_t)(4 * tn + 2 * wc) * ktiles * kScaleUnitDwords;
-  }
-  const uint32_t lane4 = (uint32_t)lane * 4;
-  auto dma_scale = [&](int kind, int kt, int slot) {
-    const uint32_t* src = ((kind == 0 || kind == 3) ? sc_a : sc_b) + ((size_t)(kind >= 2 ? ktiles : 0) + kt) * kScaleUnitDwords;
+  auto scale_base = [&](const uint32_t* S, int t, int w) { return S + (size_t)(4 * t + 2 * w) * ktiles * kScaleUnitDwords; };
+  const uint32_t* sc_a = kMx ? scale_base(SA, tm, wr) : nullptr;  // wave-uniform
+  const uint32_t* sc_b = kMx ? scale_base(SB, tn, wc) : nullptr;
+  const uint32_t* nsc_a = kMx && has_next ? scale_base(SA, ntm, wr) : sc_a;
+  const uint32_t* nsc_b = kMx && has_next ? scale_base(SB, ntn, wc) : sc_b;
+  auto dma_scale = [&](int kind, int kt, int slot, const uint32_t* sa_base, const uint32_t* sb_base) {
+    const uint32_t* src = ((kind == 0 || kind == 3) ? sa_base : sb_base) + ((size_t)(kind >= 2 ? ktiles : 0) + kt) * kScaleUnitDwords;
     const uint32_t lds = (uint32_t)(uintptr_t)(my_scales + slot * 256);
     const uint32_t* lane_src = src + lane;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(lane_src), "s"(lds) : "memory", "m0");
@@ -979,12 +1009,12 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // Prologue: half-tiles 0..7 (K-tiles 0 and 1) in flight, 0..3 landed (phases 0 and 1 read 2 and 3), 0 and 1 in registers.
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    const char* base = piece_base(j & 3, j >> 2);
+    const char* base = piece_base(j & 3, j >> 2, gA, gB);
     dma(base, j, std::integral_constant<int, 0>{});
     dma(base, j, std::integral_constant<int, 1>{});
     dma(base, j, std::integral_constant<int, 2>{});
     dma(base, j, std::integral_constant<int, 3>{});
-    if constexpr (kMx) dma_scale(j & 3, j >> 2, j);
+    if constexpr (kMx) dma_scale(j & 3, j >> 2, j, sc_a, sc_b);
   }
   wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
   GMD_PHASE_FENCE();
@@ -1005,7 +1035,9 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // therefore keeps issuing (the last K-tile again, into slots nobody reads any more) and keeps reading
   // (fragments nobody multiplies), which also keeps every vmcnt immediate the same.
   const int last_kt = (int)(row_bytes / BKB) - 1;
-  auto phase = [&](auto PH, int kt0) {
+  constexpr int kStoresW4 = EPI ? 32 : 64;  // store instructions per wave of one tile (store_acc<8>)
+  static_assert(kPerHalf * (kAheadW4 - 4) + kStoresW4 <= 63, "vmcnt is a six-bit counter");
+  auto phase = [&](auto PH, int kt0, bool after_epilogue) {
     constexpr int P = decltype(PH)::value;
     constexpr int par = P >> 2, p = P & 3;
     constexpr int MB0 = (p >= 2) ? 4 : 0, NB0 = (p == 1 || p == 2) ? 4 : 0;
@@ -1015,9 +1047,22 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     constexpr int R = P + 2, rk = R & 3, rpar = (R >> 2) & 1;
     i32x8(&Rf)[4] = rk == 0 ? aL : rk == 3 ? aH : (rk == 1) == (rpar == 0) ? bX : bY;
     constexpr int rslot = R & 7;
-    // issued during this phase: half-tile P+8, into the slot half-tile P leaves
-    const int ikt = min(kt0 + 2 + par, last_kt);
-    const char* base = piece_base(p, ikt);
+    // issued during this phase: half-tile P+8, into the slot half-tile P leaves.  Beyond the end of the tile that is
+    // the next tile's K-tile 0 or 1 (stream, with a successor) or the last K-tile again (slots nobody reads any more).
+    int ikt = kt0 + 2 + par;
+    const char* pa = gA;
+    const char* pb = gB;
+    const uint32_t* psa = sc_a;
+    const uint32_t* psb = sc_b;
+    if (ikt > last_kt) {
+      if (has_next) {
+        ikt -= last_kt + 1;
+        pa = nA, pb = nB, psa = nsc_a, psb = nsc_b;
+      } else {
+        ikt = last_kt;
+      }
+    }
+    const char* base = piece_base(p, ikt, pa, pb);
     int& sAf = (p < 2) ? sAL : sAH;
     int& sBf = (p == 0 || p == 3) ? (par ? sBY : sBX) : (par ? sBX : sBY);
     int& sRf = rk == 0 ? sAL : rk == 3 ? sAH : (rk == 1) == (rpar == 0) ? sBX : sBY;
@@ -1038,7 +1083,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
             else dma(base, P, std::integral_constant<int, 3>{});
           }
         } else if (i == 12) {
-          if constexpr (!(ABL & 2)) dma_scale(p, ikt, P);
+          if constexpr (!(ABL & 2)) dma_scale(p, ikt, P, psa, psb);
         } else if (i == 13) {
           if constexpr (!(ABL & 1)) sRf = read_scale(rslot);
         }
@@ -1076,7 +1121,11 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     // phases: after odd phase h, half-tiles up to h+4 have landed (h+1 and h+2 read h+3 and h+4) and the reads
     // of phases h-1 and h are done, which frees the slots that phases h+1 and h+2 refill.
     if constexpr (P & 1) {
-      wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
+      // Behind an epilogue the tile's stores sit between half-tiles 7 and 8 in the memory queue: the waits of phases
+      // 1 and 3 are for half-tiles older than the stores and let them stay outstanding; from phase 5 on the awaited
+      // half-tile is younger than the stores and the plain count is the right one.
+      if (STREAM && (P == 1 || P == 3) && after_epilogue) wait_vmcnt<kPerHalf * (kAheadW4 - 4) + kStoresW4>();
+      else wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if constexpr (!(ABL & 32)) GMD_PHASE_FENCE();
     } else {
@@ -1085,16 +1134,52 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   };
 
   const int npairs = (int)(row_bytes / BKB) >> 1;
-  for (int it = 0; it < npairs; it++) {
-    const int kt0 = 2 * it;
-    phase(std::integral_constant<int, 0>{}, kt0);
-    phase(std::integral_constant<int, 1>{}, kt0);
-    phase(std::integral_constant<int, 2>{}, kt0);
-    phase(std::integral_constant<int, 3>{}, kt0);
-    phase(std::integral_constant<int, 4>{}, kt0);
-    phase(std::integral_constant<int, 5>{}, kt0);
-    phase(std::integral_constant<int, 6>{}, kt0);
-    phase(std::integral_constant<int, 7>{}, kt0);
+  bool after_epilogue = false;
+  for (;;) {
+    for (int it = 0; it < npairs; it++) {
+      const int kt0 = 2 * it;
+      const bool ae = after_epilogue && it == 0;
+      phase(std::integral_constant<int, 0>{}, kt0, ae);
+      phase(std::integral_constant<int, 1>{}, kt0, ae);
+      phase(std::integral_constant<int, 2>{}, kt0, ae);
+      phase(std::integral_constant<int, 3>{}, kt0, ae);
+      phase(std::integral_constant<int, 4>{}, kt0, ae);
+      phase(std::integral_constant<int, 5>{}, kt0, ae);
+      phase(std::integral_constant<int, 6>{}, kt0, ae);
+      phase(std::integral_constant<int, 7>{}, kt0, ae);
+    }
+    if constexpr (!STREAM) break;
+    // Tile boundary: the next tile's half-tiles 0..7 are in flight or landed, its fragments 0 and 1 in registers.
+    // The last tile goes through the same code: a second copy of the epilogue behind the loop would have its
+    // conversions merged with this one's and hoisted above the branch between them, all 128 results live at once.
+    __builtin_amdgcn_sched_barrier(0);
+    W4_DRAIN();
+    __builtin_amdgcn_sched_barrier(0);
+    // The accumulators are made opaque first: with the K loop's "never entered" path in view the compiler folds
+    // the conversions into the two incoming edges (constants on one, all 128 results ahead of the first store on
+    // the other) and spills the K loop's own registers to make room.
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) asm volatile("" : "+a"(acc[i][j]));
+    store_acc<8, EPI, true>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
+    if (!has_next) break;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    W4_DRAIN();
+    __builtin_amdgcn_sched_barrier(0);
+    wgid += tile_step;
+    tm = ntm, tn = ntn, gA = nA, gB = nB;
+    if constexpr (kMx) sc_a = nsc_a, sc_b = nsc_b;
+    look_ahead();
+    if constexpr (kMx) {
+      nsc_a = has_next ? scale_base(SA, ntm, wr) : sc_a;
+      nsc_b = has_next ? scale_base(SB, ntn, wc) : sc_b;
+    }
+    after_epilogue = true;
   }
   wait_vmcnt<0>();  // the last pair's surplus DMA must not outlive the workgroup's LDS
   __builtin_amdgcn_sched_barrier(0);
@@ -1110,7 +1195,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   }
 #endif
 
-  store_acc<8, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
+  if constexpr (!STREAM) store_acc<8, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
 }
 
 // ---- output checksum (integer, order-independent -> bitwise reproducible) ----
@@ -1327,9 +1412,10 @@ double peak_flops_per_mfma(int dt) {
 // Which GEMM schedule runs: -1 = the fastest for the dtype and shape (default); 0 = the simple double-buffered
 // loop (A/B baseline; also what odd K-tile counts run); 1 = eight waves of 128 x 64, one workgroup per tile;
 // 2 = four waves of 128 x 128; 3 = eight waves of 128 x 64 as one stream per CU over its tiles (gemm_ps_kernel);
-// 4 / 5 = schedule 1 with the narrow / the wide but cached epilogue (A/B references for store_acc).
+// 4 / 5 = schedule 1 with the narrow / the wide but cached epilogue (A/B references for store_acc);
+// 6 = four waves of 128 x 128 as one stream per CU over its tiles (gemm_w4_kernel<.., STREAM>).
 constexpr int kVariantUnset = -2;
-constexpr int kVariantMax = 5;
+constexpr int kVariantMax = 6;
 int g_gemm_variant = kVariantUnset;
 
 int gemm_variant() {
@@ -1434,6 +1520,9 @@ int launch_gemm_t(const GemmArgs& g) {
       case 69: return launch_lds(gemm_w4_kernel<DT, 16 | (2 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 4 apart
       case 70: return launch_lds(gemm_w4_kernel<DT, 16 | (3 << 8)>, grid, kThreadsW4, w4_lds, g);  // pieces 5 apart from 12
       case 71: return launch_lds(gemm_w4_kernel<DT, 16 | (4 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 3 apart
+      case 72:  // the stream with cached stores
+        if (stream_ok) return launch_lds(gemm_w4_kernel<DT, 0, 2, true>, persistent_grid(), kThreadsW4, w4_lds, g);
+        break;
       default: break;
     }
   }
@@ -1444,10 +1533,13 @@ int launch_gemm_t(const GemmArgs& g) {
   int variant = gemm_variant();
   if (variant < 0 || variant > kVariantMax)
     variant = (kMx || DT == GMD_DT_FP8) ? 2 : (size_t)grid <= 4 * (size_t)persistent_grid() ? 2 : 3;
-  if (kMx && variant != 0) variant = 2;
+  if (kMx && variant != 0 && variant != 6) variant = 2;
   if (!pairs) variant = 0;
   if (variant == 3 && !stream_ok) variant = 1;
+  if (variant == 6 && !stream_ok) variant = 2;
   if (variant == 2) return launch_lds(gemm_w4_kernel<DT>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
+  if (variant == 6)
+    return launch_lds(gemm_w4_kernel<DT, 0, 1, true>, persistent_grid(), kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
   if constexpr (!kMx) {
     switch (variant) {
       case 1: GMD_LAUNCH((gemm_pp_kernel<DT>), grid, kThreads);
@@ -1468,7 +1560,7 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 71)) {
+      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 72)) {
     g_gemm_variant = variant;
     return GMD_OK;
   }

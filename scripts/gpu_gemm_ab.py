@@ -11,6 +11,11 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("GEMM_AB_ABLATE"):  # the ablation build (make diag-ablate) carries the extra arms (variants > 6)
+    from k8s_gpu_monitor_amd import _lib
+
+    _orig_find = _lib._find
+    _lib._find = lambda name: _orig_find("libgpumon_diag_ablate.so" if name == "libgpumon_diag.so" else name)
 from k8s_gpu_monitor_amd.ops import diag  # noqa: E402
 
 dev = torch.device("cuda", 0)

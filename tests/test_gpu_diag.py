@@ -230,7 +230,7 @@ def test_mx_scales_are_applied_per_row_and_per_block_of_32(diag, dev):
     diag.mx_pack_scales(sb.data_ptr(), pb.data_ptr(), n, k, _stream())
     c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
     try:
-        for variant in (0, 2):
+        for variant in (0, 2, 6):
             diag.gemm_set_variant(variant)
             diag.gemm_launch("mxfp8", one.data_ptr(), one.data_ptr(), c.data_ptr(), m, n, k, _stream(), scale_a=pa.data_ptr(),
                              scale_b=pb.data_ptr())
@@ -256,32 +256,32 @@ def test_mx_scales_are_applied_per_row_and_per_block_of_32(diag, dev):
 @pytest.mark.parametrize("dtype", ["bf16", "fp8", "mxfp8"])
 def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
     """The pipelined schedules (eight waves x 128x64 per tile, the same as one stream per CU over its
-    tiles, four waves x 128x128 with AGPR accumulators, the narrow and the cached epilogue) and the simple
+    tiles, four waves x 128x128 with AGPR accumulators, per tile and as a stream, the narrow and the cached epilogue) and the simple
     double-buffered loop add the same products in the same order, so their outputs are identical; repeated
     launches of a pipeline must not differ either (a race between LDS-DMA and fragment reads, a store
     counted as a landed fetch, or a missed wait state around the hand-placed MFMAs, would show as
     run-to-run differences).  K-tile counts of 2 (prologue + one pair), 4, 32 and 128 exercise the loop
     entry and the surplus issue of the last pair; an odd number of K-tiles takes the fallback path.
-    MX-fp8 has two schedules (simple loop, four waves); the others fall back to the four-wave one."""
+    MX-fp8 has three schedules (simple loop, four waves per tile and as a stream); the others fall back to the four-wave one."""
     kt = 64 if dtype == "bf16" else 128  # elements per 128-byte K-tile
     try:
         for (m, n, k) in [(512, 512, 2 * kt), (256, 512, 4 * kt), (512, 512, 32 * kt), (1024, 768, 128 * kt), (256, 256, 3 * kt),
                           (4352, 4352, 4 * kt), (4352, 4608, 10 * kt)]:  # 289 / 306 tiles: more than CUs, variant 3 streams
             G = _Gemm(diag, dev, m, n, k, dtype, seed=k)
             outs = {}
-            for variant in (0, 1, 2, 3, 4, 5, -1):
+            for variant in (0, 1, 2, 3, 4, 5, 6, -1):
                 diag.gemm_set_variant(variant)
                 c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
                 G.launch(c)
                 torch.cuda.synchronize()
                 outs[variant] = c
-                if variant in (1, 2, 3):  # 4 and 5 differ from 1 in the epilogue only
+                if variant in (1, 2, 3, 6):  # 4 and 5 differ from 1 in the epilogue only
                     c2 = torch.empty_like(c)
                     for _ in range(20):
                         G.launch(c2)
                     torch.cuda.synchronize()
                     assert torch.equal(c2, c), (variant, m, n, k)
-            for variant in (1, 2, 3, 4, 5, -1):
+            for variant in (1, 2, 3, 4, 5, 6, -1):
                 assert torch.equal(outs[0], outs[variant]), (variant, m, n, k)
         with pytest.raises(diag.DiagError):
             diag.gemm_set_variant(9)
