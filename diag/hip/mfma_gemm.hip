@@ -153,6 +153,35 @@ __device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* _
   }
 }
 
+// Store a wave's 128 x 128 accumulators as bf16 when the operand rows were dealt out so that the MFMA's lane index
+// runs along C's contiguous dimension (see gemm_w4_kernel): block (mb, nb) holds, in lane (fr, fq) and register r, the
+// element of tile row (4 fq + r) * 8 + mb and column fr * 8 + nb.  A lane's eight nb blocks are eight consecutive
+// columns, 16 bytes, and the sixteen lanes of one fq are one whole 256-byte row of the wave's tile: every quad of
+// lanes writes 64 contiguous bytes.  With store_acc's layout (neighbouring lanes = neighbouring ROWS) the address
+// path takes one lane per cycle: 7.9 k cycles for the 32 stores of four waves, cached or not, against 2 k at 64 B/clk.
+template <int EPI, bool PACE = false>
+__device__ __forceinline__ void store_acc_rows(const f32x4 (&acc)[8][8], __bf16* __restrict__ C, size_t ldc, int row0, int col0,
+                                               int fr, int fq) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  __bf16* const base = C + (size_t)(row0 + fq * 32) * ldc + col0 + fr * 8;
+#pragma unroll
+  for (int mb = 0; mb < 8; mb++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      u32x4 o;
+#pragma unroll
+      for (int h = 0; h < 4; h++)
+        o[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{acc[mb][2 * h][r], acc[mb][2 * h + 1][r]}, bf16x2));
+      u32x4* dst = (u32x4*)(base + (size_t)(r * 8 + mb) * ldc);
+      if constexpr (EPI == 1) __builtin_nontemporal_store(o, dst);
+      else *dst = o;
+    }
+    if constexpr (PACE) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes,
@@ -872,7 +901,7 @@ __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x
 #define W4_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 // ABL (ablation builds only; results are wrong, timing is the point): 1 no fragment reads, 2 no DMA, 4 no MFMAs,
-// 16 clock stamps, 32 no barriers.  EPI: see store_acc.
+// 16 clock stamps, 32 no barriers, 128 (with 16) the stamps say when and on which CU instead of how long.  EPI: see store_acc.
 // STREAM: one workgroup per CU walks the tiles j, j + G/8, ... of its XCD's chunk without draining the ring: the
 // half-tiles a tile's last pair issues and reads beyond its end are the first ones of the next tile (they land in
 // the slots and registers that tile's first pair expects), so a tile boundary is the epilogue and nothing else.
@@ -926,22 +955,30 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   };
   look_ahead();
 
-  // Staging: this wave fills pieces 4*wave .. 4*wave+3 (8 rows x 128 B each) of every slot.  Slot-local row l is
-  // tile row (l>>6)*128 + (l&63) [+64 for hi], for A and B alike.
+  // Staging: this wave fills pieces 4*wave .. 4*wave+3 (8 rows x 128 B each) of every slot, for A and B alike.
+  // MX-fp8: slot-local row l is tile row (l>>6)*128 + (l&63) [+64 for hi] (the order the packed scales are in).
+  // bf16 and fp8 (kRowsDealt): slot-local row l = 64 w + 16 c + f is tile row 128 w + 8 f + c [+4 for hi], so that
+  // fragment lane f of block c (c + 4 in the hi half) holds row or column 8 f + c of the wave's 128: with A as the
+  // MFMA's first operand the result lane (fr, fq), register r of block (mb, nb) is row (4 fq + r) * 8 + mb, column
+  // fr * 8 + nb, and the epilogue stores whole rows from neighbouring lanes (store_acc_rows).  The fragment reads and
+  // the LDS image are the same either way; only the global row a DMA lane fetches differs.
+  constexpr bool kRowsDealt = !kMx && EPI != 0;
   const int r8 = lane >> 3;
   const uint32_t src_chunk = (uint32_t)(((lane & 7) ^ chunk_swizzle<DT>(r8)) * 16);
   uint32_t off[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int l = (4 * wave + i) * 8 + r8;
-    off[i] = (uint32_t)(((l >> 6) * 128 + (l & 63)) * row_bytes) + src_chunk;
+    const int tile_row = kRowsDealt ? (l >> 6) * 128 + (l & 15) * 8 + ((l & 63) >> 4) : (l >> 6) * 128 + (l & 63);
+    off[i] = (uint32_t)(tile_row * row_bytes) + src_chunk;
   }
-  const size_t hi_off = 64 * row_bytes;
+  const size_t hi_off = (kRowsDealt ? 4 : 64) * row_bytes;
   char* const my_pieces = smem + wave * 4096;
 
   // kind: 0 A-lo, 1 B-lo, 2 B-hi, 3 A-hi.  Wave-uniform part of the source address of one half-tile, kept in SGPRs.
+  constexpr int kOffBias = 3 * 1024;
   auto piece_base = [&](int kind, int kt, const char* pa, const char* pb) {
-    const char* base = ((kind == 0 || kind == 3) ? pa : pb) + ((kind >= 2) ? hi_off : 0) + (size_t)kt * BKB;
+    const char* base = ((kind == 0 || kind == 3) ? pa : pb) + ((kind >= 2) ? hi_off : 0) + (size_t)kt * BKB - kOffBias;
     asm volatile("" : "+s"(base));
     return base;
   };
@@ -950,9 +987,11 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // i KiB taken off to make up for the immediate on the global side).  Through the builtin every piece costs a 64-bit
   // VALU add and an M0 write of its own, and with one wave per SIMD a VALU instruction is an MFMA issue slot lost
   // (measured: 12 k of 293 k cycles per tile).
+  // The VGPR offset is unsigned: a piece whose first row is low in the tile (any piece but the first, once the rows are
+  // dealt) would wrap below zero, so every offset carries a bias that the SGPR base gives back (piece_base).
   uint32_t off_imm[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) off_imm[i] = off[i] - (uint32_t)(i * 1024);
+  for (int i = 0; i < 4; i++) off_imm[i] = off[i] + (uint32_t)(kOffBias - i * 1024);
   auto dma = [my_pieces, o0 = off_imm[0], o1 = off_imm[1], o2 = off_imm[2], o3 = off_imm[3]](const char* base, int slot, auto I) {
     constexpr int i = decltype(I)::value;
     const uint32_t lds = (uint32_t)(uintptr_t)(my_pieces + slot * kHalfBytes);
@@ -1028,15 +1067,21 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   GMD_PHASE_FENCE();
+#ifdef GMD_GEMM_ABLATE
+  unsigned long long stamp_s1 = 0, stamp_s2 = 0;  // shader ticks: prologue done, K loop done (before the last wait)
+  if constexpr (ABL & 16) stamp_s1 = __builtin_amdgcn_s_memtime();
+#endif
 
   // One phase.  P: phase within a pair of K-tiles (0..7).  There is ONE loop body and no specialised last
   // iteration: hipcc allocates a separate tail separately and bridges the two with v_accvgpr copies placed
   // right against the asm MFMAs, whose wait states it cannot see (measured: wrong sums).  The last pair
-  // therefore keeps issuing (the last K-tile again, into slots nobody reads any more) and keeps reading
-  // (fragments nobody multiplies), which also keeps every vmcnt immediate the same.
+  // therefore keeps issuing (the last K-tile again, into slots nobody reads any more; those fetches hit in L2 and have
+  // landed by the end of the pair: the wait behind the loop measures 136 cycles) and keeps reading (fragments nobody
+  // multiplies), which also keeps every vmcnt immediate the same.  Branching round the surplus DMA under a wave-uniform
+  // flag was tried: four s_cmp + s_cbranch per phase, never taken before the last pair, cost 10 % of the K loop.
   const int last_kt = (int)(row_bytes / BKB) - 1;
   constexpr int kStoresW4 = EPI ? 32 : 64;  // store instructions per wave of one tile (store_acc<8>)
-  static_assert(kPerHalf * (kAheadW4 - 4) + kStoresW4 <= 63, "vmcnt is a six-bit counter");
+  static_assert(!STREAM || kPerHalf * (kAheadW4 - 4) + kStoresW4 <= 63, "vmcnt is a six-bit counter");
   auto phase = [&](auto PH, int kt0, bool after_epilogue) {
     constexpr int P = decltype(PH)::value;
     constexpr int par = P >> 2, p = P & 3;
@@ -1070,7 +1115,11 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 #pragma unroll
     for (int i = 0; i < NM; i++) {
       const int sub = i >> 4, mb = (i >> 2) & 3, nb = i & 3;
-      if constexpr (!(ABL & 4)) mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], sub, mb, nb, sAf, sBf);
+      if constexpr (!(ABL & 4)) {
+        // mfma_step's first matrix operand is its `b`: rows dealt -> A goes first (result lanes run along N)
+        if constexpr (kRowsDealt) mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Bf[nb], Af[mb], sub, nb, mb, sBf, sAf);
+        else mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], sub, mb, nb, sAf, sBf);
+      }
       if constexpr (kMx) {
         // sixteen MFMAs per phase: reads behind the first eight, then the four pieces, the scale unit, the scale read
         if (i < 8) {
@@ -1162,7 +1211,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     for (int i = 0; i < 8; i++)
 #pragma unroll
       for (int j = 0; j < 8; j++) asm volatile("" : "+a"(acc[i][j]));
-    store_acc<8, EPI, true>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
+    if constexpr (kRowsDealt) store_acc_rows<EPI, true>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq);
+    else store_acc<8, EPI, true>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
     if (!has_next) break;
 #pragma unroll
     for (int i = 0; i < 8; i++)
@@ -1181,13 +1231,21 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     }
     after_epilogue = true;
   }
+#ifdef GMD_GEMM_ABLATE
+  if constexpr (ABL & 16) {
+    asm volatile("s_nop 0" ::"v"(a_off[0]));
+    stamp_s2 = __builtin_amdgcn_s_memtime();
+  }
+#endif
   wait_vmcnt<0>();  // the last pair's surplus DMA must not outlive the workgroup's LDS
   __builtin_amdgcn_sched_barrier(0);
   W4_DRAIN();
   __builtin_amdgcn_sched_barrier(0);
 #ifdef GMD_GEMM_ABLATE
+  unsigned long long stamp_s3 = 0;
   if constexpr (ABL & 16) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    stamp_s3 = t1;
     if (threadIdx.x == 0 && wgid < kStampSlots) {
       g_gemm_stamps[2 * wgid] = t1 - stamp_t0;
       g_gemm_stamps[2 * wgid + 1] = r1 - stamp_r0;
@@ -1195,7 +1253,36 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   }
 #endif
 
-  if constexpr (!STREAM) store_acc<8, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
+  if constexpr (!STREAM) {
+    if constexpr (kRowsDealt) store_acc_rows<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq);
+    else store_acc<8, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
+  }
+#ifdef GMD_GEMM_ABLATE
+  if constexpr (ABL & 16) {
+    // Timeline of the tile in shader ticks from the kernel's first instruction: prologue done, K loop done, last
+    // DMA landed, last store issued.
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+    if constexpr (ABL & 128) {
+      // Where and when the workgroup ran: 100 MHz real-time at its first instruction and behind its last store, and the
+      // HW_ID register (CU, shader engine, XCC) of wave 0, to line up the workgroups that followed one another on a CU.
+      const unsigned long long r4 = __builtin_amdgcn_s_memrealtime();
+      const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
+      const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID, 4 bits
+      if (threadIdx.x == 0 && wgid < kStampSlots) {
+        g_gemm_timeline[4 * wgid] = stamp_r0;
+        g_gemm_timeline[4 * wgid + 1] = r4;
+        g_gemm_timeline[4 * wgid + 2] = ((unsigned long long)xcc << 32) | hw;
+        g_gemm_timeline[4 * wgid + 3] = s4 - stamp_t0;
+      }
+    } else if (threadIdx.x == 0 && wgid < kStampSlots) {
+      g_gemm_timeline[4 * wgid] = stamp_s1 - stamp_t0;
+      g_gemm_timeline[4 * wgid + 1] = stamp_s2 - stamp_t0;
+      g_gemm_timeline[4 * wgid + 2] = stamp_s3 - stamp_t0;
+      g_gemm_timeline[4 * wgid + 3] = s4 - stamp_t0;
+    }
+  }
+#endif
 }
 
 // ---- output checksum (integer, order-independent -> bitwise reproducible) ----
@@ -1520,6 +1607,9 @@ int launch_gemm_t(const GemmArgs& g) {
       case 69: return launch_lds(gemm_w4_kernel<DT, 16 | (2 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 4 apart
       case 70: return launch_lds(gemm_w4_kernel<DT, 16 | (3 << 8)>, grid, kThreadsW4, w4_lds, g);  // pieces 5 apart from 12
       case 71: return launch_lds(gemm_w4_kernel<DT, 16 | (4 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 3 apart
+      case 75: return launch_lds(gemm_w4_kernel<DT, 16 | 128>, grid, kThreadsW4, w4_lds, g);  // stamps: when and on which CU
+      case 73: return launch_lds(gemm_w4_kernel<DT, 16, 2>, grid, kThreadsW4, w4_lds, g);  // stamps, cached stores
+      case 74: return launch_lds(gemm_w4_kernel<DT, 16, 0>, grid, kThreadsW4, w4_lds, g);  // stamps, narrow cached stores
       case 72:  // the stream with cached stores
         if (stream_ok) return launch_lds(gemm_w4_kernel<DT, 0, 2, true>, persistent_grid(), kThreadsW4, w4_lds, g);
         break;
@@ -1527,12 +1617,11 @@ int launch_gemm_t(const GemmArgs& g) {
     }
   }
 #endif
-  // auto, by measurement (scripts/gpu_gemm_ab.py): MX-fp8 runs the four-wave kernel, the only pipeline that carries
-  // scales; unscaled fp8 runs it too (1-2 % ahead of the eight-wave kernels at 4096..16384); bf16 runs it up to four
-  // tiles per CU (0.5-2 % ahead at 4096 and 8192) and the eight-wave stream beyond (0.7 % ahead at 16384).
+  // auto, by measurement (scripts/gpu_gemm_ab.py): the four-wave kernel for every data type and shape it covers.  It is
+  // the only pipeline that carries MX scales, and since its epilogue stores whole rows from neighbouring lanes it is
+  // ahead of the eight-wave kernels on bf16 and fp8 at 4096 (4-6 %), 8192 (0.5-1.6 %) and 16384 (0.6-1.1 %) alike.
   int variant = gemm_variant();
-  if (variant < 0 || variant > kVariantMax)
-    variant = (kMx || DT == GMD_DT_FP8) ? 2 : (size_t)grid <= 4 * (size_t)persistent_grid() ? 2 : 3;
+  if (variant < 0 || variant > kVariantMax) variant = 2;
   if (kMx && variant != 0 && variant != 6) variant = 2;
   if (!pairs) variant = 0;
   if (variant == 3 && !stream_ok) variant = 1;
@@ -1560,7 +1649,7 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 72)) {
+      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 75)) {
     g_gemm_variant = variant;
     return GMD_OK;
   }

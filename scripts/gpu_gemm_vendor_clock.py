@@ -1,7 +1,9 @@
 """Launch list for a rocprofv3 counter pass that compares the clock the chip holds under this
 repository's bf16 GEMM and under hipBLASLt's (torch.matmul), same operands, same process:
     rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d OUT -- python3 scripts/gpu_gemm_vendor_clock.py
-Effective clock of a dispatch = GRBM_GUI_ACTIVE / 8 / duration (the counter sums the 8 XCDs)."""
+Effective clock of a dispatch = GRBM_GUI_ACTIVE / 8 / duration (the counter sums the 8 XCDs).
+GEMM_VC_REPS (default 3) and GEMM_VC_LAUNCHES (default 150) shorten it for other counter passes
+(instruction mix, L2 traffic: scripts/gpu_gemm_vendor_pmc.sh)."""
 import os
 import sys
 
@@ -17,12 +19,14 @@ a = torch.randn(s, s, device=dev).bfloat16()
 b = torch.randn(s, s, device=dev).bfloat16()
 c = torch.empty(s, s, dtype=torch.bfloat16, device=dev)
 bt = b.t()
-for rep in range(3):  # interleaved blocks of launches, long enough for the clock to settle
+REPS = int(os.environ.get("GEMM_VC_REPS", "3"))
+LAUNCHES = int(os.environ.get("GEMM_VC_LAUNCHES", "150"))
+for rep in range(REPS):  # interleaved blocks of launches, long enough for the clock to settle
     for v in (3, 1, 2):
         diag.gemm_set_variant(v)
-        for _ in range(150):
+        for _ in range(LAUNCHES):
             diag.gemm_launch("bf16", a.data_ptr(), b.data_ptr(), c.data_ptr(), s, s, s, stream)
-    for _ in range(150):
+    for _ in range(LAUNCHES):
         torch.matmul(a, bt, out=c)
     torch.cuda.synchronize()
 print("done")
