@@ -155,7 +155,9 @@ GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double s
                             gmd_mfma_result_t* out);
 /* One GEMM on caller memory.  A: [M,K] row-major, B: [N,K] row-major (i.e. B^T), C: [M,N] row-major bf16.
  * GMD_DT_BF16: A, B bf16.  GMD_DT_FP8: A, B OCP e4m3, unscaled (mfma_f32_16x16x32_fp8_fp8).
- * M, N multiples of 256; K a multiple of 64 (bf16) / 128 (fp8).  GMD_DT_MXFP8 needs scales: gmd_gemm_launch_mx. */
+ * M, N multiples of 8 (tiles that reach beyond the matrix and odd K-tile counts run a general instantiation of the
+ * four-wave kernel); K a multiple of 64 (bf16) / 128 (fp8), i.e. whole 128-byte K-tiles.  GMD_DT_MXFP8 needs scales
+ * and M, N in multiples of 256: gmd_gemm_launch_mx. */
 GMD_API int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream);
 /* OCP MX-fp8 GEMM: e4m3 elements with one E8M0 scale (2^(e-127)) per row and 32 consecutive k, on the
  * block-scaled MFMA (mfma_scale_f32_16x16x128_f8f6f4).  The scale tensors are in the packed form that
@@ -169,8 +171,8 @@ GMD_API int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int r
  * 1 = eight waves x 128x64, one workgroup per tile; 2 = four waves x 128x128 with the accumulators in AGPRs;
  * 3 = eight waves x 128x64 as one stream per CU over its tiles (needs more tiles than CUs and >= 4 K-tiles);
  * 4 / 5 = schedule 1 with the narrow / the cached epilogue (A/B references); 6 = schedule 2 as one stream per
- * CU (A/B reference, same conditions as 3, otherwise 2 runs).  The pipelines need an even number of 128-byte
- * K-tiles, otherwise the launch falls back to 0.  MX-fp8 runs 2, 6 or 0.  All schedules give
+ * CU (A/B reference, same conditions as 3, otherwise 2 runs).  Partial tiles run the general four-wave kernel
+ * whatever the schedule, an odd number of K-tiles does unless the schedule is 0.  MX-fp8 runs 2, 6 or 0.  All schedules give
  * bit-identical results.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
 

@@ -182,6 +182,36 @@ __device__ __forceinline__ void store_acc_rows(const f32x4 (&acc)[8][8], __bf16*
   }
 }
 
+// store_acc_rows for a tile that reaches beyond M or N: the same stores, each behind its own bounds test.
+template <int EPI>
+__device__ __forceinline__ void store_acc_rows_edge(const f32x4 (&acc)[8][8], __bf16* __restrict__ C, size_t ldc, int row0, int col0,
+                                                    int fr, int fq, int M, int N) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const int col = col0 + fr * 8;
+#pragma unroll
+  for (int mb = 0; mb < 8; mb++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = row0 + fq * 32 + r * 8 + mb;
+      u32x4 o;
+#pragma unroll
+      for (int h = 0; h < 4; h++)
+        o[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{acc[mb][2 * h][r], acc[mb][2 * h + 1][r]}, bf16x2));
+      if (row < M && col < N) {  // N is a multiple of 8: a lane's eight columns are inside or outside together
+        u32x4* dst = (u32x4*)(C + (size_t)row * ldc + col);
+        if constexpr (EPI == 1) __builtin_nontemporal_store(o, dst);
+        else *dst = o;
+      }
+    }
+  }
+}
+
+// What the LDS-DMA of a K-tile beyond the last one reads when the K-tile count is odd (the pipelines walk K-tiles in
+// pairs): zeros for both operands, so that the pair's second half adds nothing.
+__device__ uint4 g_gemm_zero_slab[256];
+
 template <int DT>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes,
@@ -908,7 +938,10 @@ __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x
 // Measured 1-3 % slower than one workgroup per tile: the one vmcnt counter retires loads, stores and LDS-DMA in order,
 // so the first half-tile issued behind a tile's stores waits for the store burst of all CUs to drain, which the ring
 // covers only in part, while a workgroup that ends after its stores never waits for them.  Kept as an A/B reference.
-template <int DT, int ABL = 0, int EPI = 1, bool STREAM = false>
+// GEN: any M, any N that is a multiple of 8 (bf16, fp8), any number of K-tiles.  Rows beyond the matrix are fetched
+// from its last row (their products land in accumulators that are never stored), stores are bounds-tested, and an odd
+// K-tile count is completed by a K-tile of zeros.  The full-tile, even-count instantiation pays for none of it.
+template <int DT, int ABL = 0, int EPI = 1, bool STREAM = false, bool GEN = false>
 __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                              __bf16* __restrict__ C, int M, int N, size_t row_bytes,
                                                              const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB) {
@@ -928,7 +961,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 
   // Per-tile launch: workgroup = tile.  Stream: XCD x owns a contiguous chunk of tiles, its workgroup j walks tiles
   // j, j + G/8, ... of the chunk.
-  const int tiles_m = M / BM, tiles_n = N / BN;
+  static_assert(!(GEN && STREAM), "the stream walks full tiles and even K-tile counts only");
+  const int tiles_m = GEN ? (M + BM - 1) / BM : M / BM, tiles_n = GEN ? (N + BN - 1) / BN : N / BN;
   const int nunits = STREAM ? tiles_m * tiles_n : (int)gridDim.x;
   const int xcd = blockIdx.x & 7, q8 = nunits >> 3, r8n = nunits & 7;
   const int chunk0 = xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8;
@@ -965,14 +999,26 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   constexpr bool kRowsDealt = !kMx && EPI != 0;
   const int r8 = lane >> 3;
   const uint32_t src_chunk = (uint32_t)(((lane & 7) ^ chunk_swizzle<DT>(r8)) * 16);
-  uint32_t off[4];
+  constexpr int kHiRows = kRowsDealt ? 4 : 64;
+  uint32_t off[4], off_b[4];  // A and B fetch the same rows of their tiles, unless one of them has rows to clamp (GEN)
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int l = (4 * wave + i) * 8 + r8;
     const int tile_row = kRowsDealt ? (l >> 6) * 128 + (l & 15) * 8 + ((l & 63) >> 4) : (l >> 6) * 128 + (l & 63);
     off[i] = (uint32_t)(tile_row * row_bytes) + src_chunk;
+    off_b[i] = off[i];
+    if constexpr (GEN && kRowsDealt) {
+      // M and N are multiples of 8 and the rows are dealt in groups of eight (8 f + c: c < 4 in the lo half-tile, the same
+      // lane offset on a base four rows further on in the hi one), so a group is inside the matrix or outside as a whole:
+      // a lane whose group is outside fetches the last group inside instead.
+      const int rows_a = M - tm * BM, rows_b = N - tn * BN;
+      const int row_a = (tile_row & ~7) >= rows_a ? rows_a - 8 + (tile_row & 7) : tile_row;
+      const int row_b = (tile_row & ~7) >= rows_b ? rows_b - 8 + (tile_row & 7) : tile_row;
+      off[i] = (uint32_t)(row_a * row_bytes) + src_chunk;
+      off_b[i] = (uint32_t)(row_b * row_bytes) + src_chunk;
+    }
   }
-  const size_t hi_off = (kRowsDealt ? 4 : 64) * row_bytes;
+  const size_t hi_off = (size_t)kHiRows * row_bytes;
   char* const my_pieces = smem + wave * 4096;
 
   // kind: 0 A-lo, 1 B-lo, 2 B-hi, 3 A-hi.  Wave-uniform part of the source address of one half-tile, kept in SGPRs.
@@ -989,13 +1035,25 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // (measured: 12 k of 293 k cycles per tile).
   // The VGPR offset is unsigned: a piece whose first row is low in the tile (any piece but the first, once the rows are
   // dealt) would wrap below zero, so every offset carries a bias that the SGPR base gives back (piece_base).
-  uint32_t off_imm[4];
+  uint32_t off_imm[4], off_imm_b[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) off_imm[i] = off[i] + (uint32_t)(kOffBias - i * 1024);
-  auto dma = [my_pieces, o0 = off_imm[0], o1 = off_imm[1], o2 = off_imm[2], o3 = off_imm[3]](const char* base, int slot, auto I) {
+  for (int i = 0; i < 4; i++) {
+    off_imm[i] = off[i] + (uint32_t)(kOffBias - i * 1024);
+    off_imm_b[i] = off_b[i] + (uint32_t)(kOffBias - i * 1024);
+  }
+  // GEN: the zero K-tile is read with one offset for all four pieces (the immediate moves on by 1 KiB per piece; 4 KiB in all).
+  const uint32_t off_zero = (uint32_t)(kOffBias + lane * 16);
+  const char* const zero_base = (const char*)g_gemm_zero_slab - kOffBias;
+  // `zero`: GEN only, wave-uniform: this half-tile is the zero K-tile.  `is_b`: a compile-time constant at every call.
+  auto dma = [my_pieces, o0 = off_imm[0], o1 = off_imm[1], o2 = off_imm[2], o3 = off_imm[3], b0 = off_imm_b[0], b1 = off_imm_b[1],
+              b2 = off_imm_b[2], b3 = off_imm_b[3], off_zero](const char* base, int slot, auto I, bool is_b, bool zero) {
     constexpr int i = decltype(I)::value;
     const uint32_t lds = (uint32_t)(uintptr_t)(my_pieces + slot * kHalfBytes);
-    const uint32_t o = i == 0 ? o0 : i == 1 ? o1 : i == 2 ? o2 : o3;
+    uint32_t o = i == 0 ? o0 : i == 1 ? o1 : i == 2 ? o2 : o3;
+    if constexpr (GEN) {
+      if (is_b) o = i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3;
+      if (zero) o = off_zero;
+    }
     // Every statement names M0 as clobbered: pieces 1..3 rely on the M0 that piece 0 wrote, and the clobber is what
     // keeps the compiler from parking an M0 write of its own between them.
     if constexpr (i == 0)
@@ -1003,6 +1061,12 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
                    : "memory", "m0");
     else
       asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(i * 1024) : "memory", "m0");
+  };
+  auto constexpr_dma4 = [&](const char* base, int slot, bool is_b, bool zero) {
+    dma(base, slot, std::integral_constant<int, 0>{}, is_b, zero);
+    dma(base, slot, std::integral_constant<int, 1>{}, is_b, zero);
+    dma(base, slot, std::integral_constant<int, 2>{}, is_b, zero);
+    dma(base, slot, std::integral_constant<int, 3>{}, is_b, zero);
   };
   // MX scales: the packed unit (256 B: 64 rows x 4 blocks of one K-tile) that belongs to a half-tile travels with
   // it, by one 4-byte-per-lane LDS-DMA into this wave's own slot of a small ring behind the operand ring.
@@ -1048,12 +1112,12 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // Prologue: half-tiles 0..7 (K-tiles 0 and 1) in flight, 0..3 landed (phases 0 and 1 read 2 and 3), 0 and 1 in registers.
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    const char* base = piece_base(j & 3, j >> 2, gA, gB);
-    dma(base, j, std::integral_constant<int, 0>{});
-    dma(base, j, std::integral_constant<int, 1>{});
-    dma(base, j, std::integral_constant<int, 2>{});
-    dma(base, j, std::integral_constant<int, 3>{});
-    if constexpr (kMx) dma_scale(j & 3, j >> 2, j, sc_a, sc_b);
+    const bool zero = GEN && (j >> 2) >= ktiles;  // a single K-tile: its partner is the zero one
+    const int kt = zero ? 0 : j >> 2;
+    const char* base = piece_base(j & 3, kt, gA, gB);
+    if constexpr (GEN) base = zero ? zero_base : base;
+    constexpr_dma4(base, j, (j & 3) == 1 || (j & 3) == 2, zero);
+    if constexpr (kMx) dma_scale(j & 3, kt, j, sc_a, sc_b);
   }
   wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
   GMD_PHASE_FENCE();
@@ -1099,6 +1163,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     const char* pb = gB;
     const uint32_t* psa = sc_a;
     const uint32_t* psb = sc_b;
+    // GEN, odd K-tile count: the K-tile right behind the last one is the zero K-tile, for A and B alike
+    const bool zero = GEN && ikt == last_kt + 1 && !(last_kt & 1);
     if (ikt > last_kt) {
       if (has_next) {
         ikt -= last_kt + 1;
@@ -1108,6 +1174,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
       }
     }
     const char* base = piece_base(p, ikt, pa, pb);
+    if constexpr (GEN) base = zero ? zero_base : base;
+    constexpr bool is_b = p == 1 || p == 2;
     int& sAf = (p < 2) ? sAL : sAH;
     int& sBf = (p == 0 || p == 3) ? (par ? sBY : sBX) : (par ? sBX : sBY);
     int& sRf = rk == 0 ? sAL : rk == 3 ? sAH : (rk == 1) == (rpar == 0) ? sBX : sBY;
@@ -1126,10 +1194,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
           if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i);
         } else if (i < 12) {
           if constexpr (!(ABL & 2)) {
-            if (i == 8) dma(base, P, std::integral_constant<int, 0>{});
-            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{});
-            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{});
-            else dma(base, P, std::integral_constant<int, 3>{});
+            if (i == 8) dma(base, P, std::integral_constant<int, 0>{}, is_b, zero);
+            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{}, is_b, zero);
+            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{}, is_b, zero);
+            else dma(base, P, std::integral_constant<int, 3>{}, is_b, zero);
           }
         } else if (i == 12) {
           if constexpr (!(ABL & 2)) dma_scale(p, ikt, P, psa, psb);
@@ -1152,10 +1220,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
         if (i >= kDma0 && (i - kDma0) % kDmaStep == 0 && (i - kDma0) / kDmaStep < 4) {
           if constexpr (!(ABL & 2)) {
             const int q = (i - kDma0) / kDmaStep;
-            if (q == 0) dma(base, P, std::integral_constant<int, 0>{});
-            else if (q == 1) dma(base, P, std::integral_constant<int, 1>{});
-            else if (q == 2) dma(base, P, std::integral_constant<int, 2>{});
-            else dma(base, P, std::integral_constant<int, 3>{});
+            if (q == 0) dma(base, P, std::integral_constant<int, 0>{}, is_b, zero);
+            else if (q == 1) dma(base, P, std::integral_constant<int, 1>{}, is_b, zero);
+            else if (q == 2) dma(base, P, std::integral_constant<int, 2>{}, is_b, zero);
+            else dma(base, P, std::integral_constant<int, 3>{}, is_b, zero);
           }
         }
         if (i <= (kDma0 + 3 * kDmaStep > 7 * kReadStep ? kDma0 + 3 * kDmaStep : 7 * kReadStep)) __builtin_amdgcn_sched_barrier(0);
@@ -1182,7 +1250,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     }
   };
 
-  const int npairs = (int)(row_bytes / BKB) >> 1;
+  const int npairs = ((int)(row_bytes / BKB) + (GEN ? 1 : 0)) >> 1;
   bool after_epilogue = false;
   for (;;) {
     for (int it = 0; it < npairs; it++) {
@@ -1254,7 +1322,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 #endif
 
   if constexpr (!STREAM) {
-    if constexpr (kRowsDealt) store_acc_rows<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq);
+    if constexpr (kRowsDealt && GEN) store_acc_rows_edge<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq, M, N);
+    else if constexpr (kRowsDealt) store_acc_rows<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq);
     else store_acc<8, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
   }
 #ifdef GMD_GEMM_ABLATE
@@ -1559,10 +1628,15 @@ constexpr int kScaleRingBytes = 4 * 8 * 256;  // gemm_w4_kernel, MX-fp8: four wa
 template <int DT>
 int launch_gemm_t(const GemmArgs& g) {
   constexpr bool kMx = DT == GMD_DT_MXFP8;
-  const int grid = (g.m / BM) * (g.n / BN);
+  const bool full_tiles = g.m % BM == 0 && g.n % BN == 0;
+  const int grid = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
   const size_t ktiles = g.row_bytes / BKB;
   const bool pairs = ktiles >= 2 && (ktiles & 1) == 0;                      // the pipelines walk K-tiles in pairs
-  const bool stream_ok = pairs && ktiles >= 4 && grid > persistent_grid();  // more tiles than CUs, two pairs per tile
+  const bool stream_ok = full_tiles && pairs && ktiles >= 4 && grid > persistent_grid();  // more tiles than CUs, two pairs per tile
+  // Partial tiles or an odd number of K-tiles: the general instantiation of the four-wave kernel, whatever was asked for
+  // (schedule 0 takes any K-tile count as well, but full tiles only).
+  if (!full_tiles || (!pairs && gemm_variant() != 0))
+    return launch_lds(gemm_w4_kernel<DT, 0, 1, false, true>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
 #define GMD_LAUNCH(KFN, GRID, THREADS) return launch_lds(KFN, GRID, THREADS, kLdsBytes, g)
 #ifdef GMD_GEMM_ABLATE
   // Timing-only builds of the per-tile pipeline with parts removed (10 + mask), other issue distances (20 + d),
@@ -1687,7 +1761,10 @@ int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles) {
 
 static int gemm_launch_checked(int dtype, const void* a, const void* b, const void* sa, const void* sb, void* c, int m, int n, int k,
                                void* hip_stream) {
-  if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || (m % BM) || (n % BN)) return GMD_ERR_BADPARAM;
+  // bf16 and fp8: M and N in multiples of 8 (a lane stores eight columns; rows are dealt to lanes in groups of eight);
+  // MX-fp8: whole 256 x 256 tiles (the packed scales come in units of 64 rows).  K in whole 128-byte K-tiles.
+  const int mn_step = dtype == GMD_DT_MXFP8 ? BM : 8;
+  if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || (m % mn_step) || (n % mn_step)) return GMD_ERR_BADPARAM;
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return GMD_ERR_BADPARAM;
   GemmArgs g{a, b, c, m, n, 0, (const uint32_t*)sa, (const uint32_t*)sb, (hipStream_t)hip_stream};
   switch (dtype) {
@@ -1732,7 +1809,7 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
   const bool fp8 = dtype == GMD_DT_FP8 || dtype == GMD_DT_MXFP8;
   const bool mx = dtype == GMD_DT_MXFP8;
   if (dtype != GMD_DT_BF16 && !fp8) return GMD_ERR_BADPARAM;
-  if (m <= 0 || n <= 0 || k <= 0 || (m % BM) || (n % BN) || (k % (fp8 ? 128 : 64))) return GMD_ERR_BADPARAM;
+  if (m <= 0 || n <= 0 || k <= 0 || (m % (mx ? BM : 8)) || (n % (mx ? BN : 8)) || (k % (fp8 ? 128 : 64))) return GMD_ERR_BADPARAM;
   GMD_HIP(hipSetDevice(device));
   const size_t esz = fp8 ? 1 : 2;
   gmd::DeviceBuffer a, b, c, sums, sa_nat, sb_nat, sa_pk, sb_pk, refs;

@@ -14,7 +14,7 @@ from k8s_gpu_monitor_amd.ops import diag  # noqa: E402
 
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-s = 8192
+s = int(os.environ.get("GEMM_VC_SIZE", "8192"))
 a = torch.randn(s, s, device=dev).bfloat16()
 b = torch.randn(s, s, device=dev).bfloat16()
 c = torch.empty(s, s, dtype=torch.bfloat16, device=dev)

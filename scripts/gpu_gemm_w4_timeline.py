@@ -21,8 +21,8 @@ lib = diag._lib()
 lib.gmd_gemm_read_timeline.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-s = 8192
-ntiles = (s // 256) ** 2
+s = int(os.environ.get("GEMM_TL_SIZE", "8192"))
+ntiles = min((s // 256) ** 2, 4096)
 out = []
 for dtype in os.environ.get("GEMM_TL_DTYPES", "bf16,fp8").split(","):
     a = torch.randn(s, s, device=dev)
@@ -36,7 +36,7 @@ for dtype in os.environ.get("GEMM_TL_DTYPES", "bf16,fp8").split(","):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = 500
+    n = 500 if s <= 8192 else 60
     for _ in range(n):
         launch()
     e1.record()
@@ -46,7 +46,7 @@ for dtype in os.environ.get("GEMM_TL_DTYPES", "bf16,fp8").split(","):
     assert lib.gmd_gemm_read_timeline(buf, ntiles) == 0
     tl = [(buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]) for i in range(ntiles)]
     med = lambda xs: statistics.median(xs)
-    row = {"dtype": dtype, "ms_per_launch": round(ms, 4),
+    row = {"dtype": dtype, "size": s, "ms_per_launch": round(ms, 4),
            "prologue_ticks": med(t[0] for t in tl), "k_loop_ticks": med(t[1] - t[0] for t in tl),
            "last_dma_wait_ticks": med(t[2] - t[1] for t in tl), "epilogue_ticks": med(t[3] - t[2] for t in tl),
            "lifetime_ticks": med(t[3] for t in tl),

@@ -289,13 +289,60 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
         diag.gemm_set_variant(-1)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+@pytest.mark.parametrize("shape", [(8, 8, 1), (264, 248, 3), (1000, 520, 5), (256, 256, 1), (4000, 4104, 2), (2048, 24, 7),
+                                   (16, 3000, 4)])
+def test_gemm_takes_the_operators_shape(diag, dev, dtype, shape):
+    """M and N in multiples of 8 (tiles that reach beyond the matrix fetch its last rows again and store behind a
+    bounds test), any number of K-tiles (an odd count is completed by a K-tile of zeros).  The output is compared with
+    fp32 everywhere, a guard band behind C must stay untouched, and every schedule that can be asked for gives the
+    same bits (they all route to the general instantiation of the four-wave kernel; with full tiles schedule 0 runs its
+    own loop)."""
+    m, n, kt = shape
+    k = kt * (64 if dtype == "bf16" else 128)
+    G = _Gemm(diag, dev, m, n, k, dtype, seed=m + n + k)
+    guard = 4096
+    buf = torch.full((m * n + guard,), 7.0, dtype=torch.bfloat16, device=dev)
+    c = buf[:m * n].view(m, n)
+    G.launch(c)
+    torch.cuda.synchronize()
+    ref = G.ref()
+    assert torch.isfinite(c.float()).all()
+    err = (c.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    assert err < 6e-3, err
+    assert (buf[m * n:] == 7.0).all()
+    try:
+        for variant in (0, 1, 2, 3, 6):
+            diag.gemm_set_variant(variant)
+            c2 = torch.empty_like(c)
+            G.launch(c2)
+            torch.cuda.synchronize()
+            assert torch.equal(c2, c), variant
+    finally:
+        diag.gemm_set_variant(-1)
+
+
+def test_mx_gemm_takes_an_odd_number_of_k_tiles(diag, dev):
+    for (m, n, kt) in [(256, 512, 1), (512, 256, 3), (768, 256, 9)]:
+        G = _Gemm(diag, dev, m, n, kt * 128, "mxfp8", seed=kt)
+        c = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=dev)
+        G.launch(c)
+        torch.cuda.synchronize()
+        ref = G.ref()
+        err = (c.float() - ref).abs().max().item() / ref.abs().max().item()
+        assert torch.isfinite(c.float()).all() and err < 6e-3, (m, n, kt, err)
+
+
 def test_gemm_rejects_shapes_the_tiling_cannot_cover(diag, dev):
     x = torch.zeros(512, 512, dtype=torch.bfloat16, device=dev)
-    for m, n, k in [(500, 512, 512), (512, 384 + 1, 512), (512, 512, 96), (0, 512, 512)]:
+    for m, n, k in [(500, 512, 512), (512, 384 + 1, 512), (512, 512, 96), (0, 512, 512), (512, 508, 512)]:
         with pytest.raises(diag.DiagError):
             diag.gemm_launch("bf16", x.data_ptr(), x.data_ptr(), x.data_ptr(), m, n, k, _stream())
     with pytest.raises(diag.DiagError):
         diag.gemm_launch("fp8", x.data_ptr(), x.data_ptr(), x.data_ptr(), 512, 512, 192, _stream())
+    with pytest.raises(diag.DiagError):  # MX-fp8: whole tiles only (the packed scales come in units of 64 rows)
+        diag.gemm_launch("mxfp8", x.data_ptr(), x.data_ptr(), x.data_ptr(), 264, 512, 512, _stream(), scale_a=x.data_ptr(),
+                         scale_b=x.data_ptr())
 
 
 def test_gemm_stress_and_pipe_peak(diag):
