@@ -161,7 +161,7 @@ GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double s
 GMD_API int gmd_gemm_launch(int dtype, const void* a, const void* b, void* c, int m, int n, int k, void* hip_stream);
 /* OCP MX-fp8 GEMM: e4m3 elements with one E8M0 scale (2^(e-127)) per row and 32 consecutive k, on the
  * block-scaled MFMA (mfma_scale_f32_16x16x128_f8f6f4).  The scale tensors are in the packed form that
- * gmd_mx_pack_scales produces from row-major uint8 [rows][K/32] (rows a multiple of 64, K of 128; the packed
+ * gmd_mx_pack_scales produces from row-major uint8 [rows][K/32] (rows a multiple of 128, K of 128; the packed
  * tensor has the same number of bytes and must be 4-byte aligned). */
 GMD_API int gmd_gemm_launch_mx(const void* a, const void* b, const void* scale_a_packed, const void* scale_b_packed, void* c,
                                int m, int n, int k, void* hip_stream);

@@ -42,10 +42,12 @@
 //     registers 0-3 and k 64 + 16*fq .. +15 in registers 4-7 — the same two 16-byte
 //     chunks a bf16 lane reads — and supplies the scale of row fr, block fq (k 32*fq ..
 //     +31; measured with one-hot scales and operands, scripts/gpu_mx_probe.py).
-//     Scales arrive "packed": per 64 rows and per K-tile one 256-byte unit
-//     whose dword fq*16 + fr holds, in byte mb, the scale of row 16*mb + fr, block
-//     fq.  A wave reads the unit with one dword per lane and selects the byte of
-//     the 16-row block with the instruction's op_sel field: no shifts, no masks.
+//     Scales arrive "packed": per 128 rows, per half h and per K-tile one 256-byte
+//     unit whose dword fq*16 + fr holds, in byte c, the scale of row 8*fr + c + 4*h
+//     of the 128, block fq: the rows that fragment lane fr works on in the four
+//     16-row blocks c of a half-tile (rows are dealt to lanes in groups of eight, see
+//     gemm_w4_kernel).  A wave reads the unit with one dword per lane and selects the
+//     byte of the block with the instruction's op_sel field: no shifts, no masks.
 //     gmd_mx_pack_scales builds the packed form from a row-major [rows][K/32] one.
 #include <hip/hip_bf16.h>
 
@@ -105,7 +107,11 @@ __device__ __forceinline__ void stage(const char* __restrict__ g, size_t row_byt
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int piece = wave * 4 + i;
-    const char* src = g + (size_t)(piece * 8 + r8) * row_bytes + kbyte + src_chunk * 16;
+    // MX-fp8: LDS row l = 64 h' + 16 c + f (h' = l >> 6) holds tile row 128 (l >> 7) + 8 f + c + 4 (h' & 1), the order
+    // the packed scales are in; the other data types stage the rows as they come.
+    const int l = piece * 8 + r8;
+    const int row = DT == GMD_DT_MXFP8 ? 128 * (l >> 7) + 8 * (l & 15) + ((l >> 4) & 3) + 4 * ((l >> 6) & 1) : l;
+    const char* src = g + (size_t)row * row_bytes + kbyte + src_chunk * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
   }
@@ -309,11 +315,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restric
         const int sa = mb < 4 ? sa_lo : sa_hi;
 #pragma unroll
         for (int nb = 0; nb < 4; nb++) {
-          // operands are swapped (B first): the first scale belongs to B's block nb, the second to A's block mb & 3
+          // A goes first (the result's lane index then runs along N): the first scale is A's block mb & 3, the second B's block nb
           switch ((mb & 3) * 4 + nb) {
 #define GMD_MX_CASE(MBQ, NBQ)                                                                                              \
   case MBQ * 4 + NBQ:                                                                                                      \
-    acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[nb], af, acc[mb][nb], 0, 0, NBQ, sb, MBQ, sa);     \
+    acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bfr[nb], acc[mb][nb], 0, 0, MBQ, sa, NBQ, sb);     \
     break;
             GMD_MX_CASE(0, 0) GMD_MX_CASE(0, 1) GMD_MX_CASE(0, 2) GMD_MX_CASE(0, 3)
             GMD_MX_CASE(1, 0) GMD_MX_CASE(1, 1) GMD_MX_CASE(1, 2) GMD_MX_CASE(1, 3)
@@ -327,8 +333,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restric
     __syncthreads();  // next buffer landed (vmcnt(0)) and everyone is done reading this one
   }
 
-  // Epilogue: lane holds C[m][n..n+3] for m = .. + (lane&15), n = .. + (lane>>4)*4.
-  store_acc<4, 1>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 64, fq);
+  if constexpr (DT == GMD_DT_MXFP8) {
+    // Rows dealt, A first: block (mb, nb), lane (fr, fq), register r is row 8 (4 fq + r) + mb of the wave's 128 and
+    // column 8 fr + 4 (wc & 1) + nb of the 128 that waves wc and wc ^ 1 share: a lane's four nb are 8 contiguous bytes.
+    __bf16* const base = C + (size_t)(tm * BM + wr * 128 + fq * 32) * N + tn * BN + 128 * (wc >> 1) + 8 * fr + 4 * (wc & 1);
+#pragma unroll
+    for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const f32x4 v{acc[mb][0][r], acc[mb][1][r], acc[mb][2][r], acc[mb][3][r]};
+        *(bf16x4*)(base + (size_t)(r * 8 + mb) * N) = __builtin_convertvector(v, bf16x4);
+      }
+  } else {
+    // Epilogue: lane holds C[m][n..n+3] for m = .. + (lane&15), n = .. + (lane>>4)*4.
+    store_acc<4, 1>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 64, fq);
+  }
 }
 
 // ---- (2b) the same GEMM as a phase-interleaved pipeline -------------------------
@@ -988,15 +1007,14 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     }
   };
   look_ahead();
-
   // Staging: this wave fills pieces 4*wave .. 4*wave+3 (8 rows x 128 B each) of every slot, for A and B alike.
-  // MX-fp8: slot-local row l is tile row (l>>6)*128 + (l&63) [+64 for hi] (the order the packed scales are in).
-  // bf16 and fp8 (kRowsDealt): slot-local row l = 64 w + 16 c + f is tile row 128 w + 8 f + c [+4 for hi], so that
+  // The narrow epilogue (EPI 0, an A/B reference for bf16 and fp8): slot-local row l is tile row (l>>6)*128 + (l&63)
+  // [+64 for hi].  Otherwise (kRowsDealt): slot-local row l = 64 w + 16 c + f is tile row 128 w + 8 f + c [+4 for hi], so that
   // fragment lane f of block c (c + 4 in the hi half) holds row or column 8 f + c of the wave's 128: with A as the
   // MFMA's first operand the result lane (fr, fq), register r of block (mb, nb) is row (4 fq + r) * 8 + mb, column
   // fr * 8 + nb, and the epilogue stores whole rows from neighbouring lanes (store_acc_rows).  The fragment reads and
   // the LDS image are the same either way; only the global row a DMA lane fetches differs.
-  constexpr bool kRowsDealt = !kMx && EPI != 0;
+  constexpr bool kRowsDealt = EPI != 0;
   const int r8 = lane >> 3;
   const uint32_t src_chunk = (uint32_t)(((lane & 7) ^ chunk_swizzle<DT>(r8)) * 16);
   constexpr int kHiRows = kRowsDealt ? 4 : 64;
@@ -1143,6 +1161,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // landed by the end of the pair: the wait behind the loop measures 136 cycles) and keeps reading (fragments nobody
   // multiplies), which also keeps every vmcnt immediate the same.  Branching round the surplus DMA under a wave-uniform
   // flag was tried: four s_cmp + s_cbranch per phase, never taken before the last pair, cost 10 % of the K loop.
+  // So was pointing the first half of the surplus at the first K-tile of the tile that follows on this XCD (ids + 32), to
+  // have it in L2 for that workgroup's prologue: the prologue stayed at 3.2-3.4 k cycles and the K loop grew by 2.4 k.
   const int last_kt = (int)(row_bytes / BKB) - 1;
   constexpr int kStoresW4 = EPI ? 32 : 64;  // store instructions per wave of one tile (store_acc<8>)
   static_assert(!STREAM || kPerHalf * (kAheadW4 - 4) + kStoresW4 <= 63, "vmcnt is a six-bit counter");
@@ -1419,7 +1439,7 @@ __global__ void pack_scales_kernel(const uint8_t* __restrict__ nat, uint32_t* __
     const uint64_t unit = i / kScaleUnitDwords;
     const int kt = (int)(unit % ktiles), rg = (int)(unit / ktiles);
     uint32_t v = 0;
-    for (int mb = 0; mb < 4; mb++) v |= (uint32_t)nat[(size_t)(64 * rg + 16 * mb + fr) * kblocks + 4 * kt + fq] << (8 * mb);
+    for (int c = 0; c < 4; c++) v |= (uint32_t)nat[(size_t)(128 * (rg >> 1) + 8 * fr + c + 4 * (rg & 1)) * kblocks + 4 * kt + fq] << (8 * c);
     packed[i] = v;
   }
 }
@@ -1762,7 +1782,7 @@ int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles) {
 static int gemm_launch_checked(int dtype, const void* a, const void* b, const void* sa, const void* sb, void* c, int m, int n, int k,
                                void* hip_stream) {
   // bf16 and fp8: M and N in multiples of 8 (a lane stores eight columns; rows are dealt to lanes in groups of eight);
-  // MX-fp8: whole 256 x 256 tiles (the packed scales come in units of 64 rows).  K in whole 128-byte K-tiles.
+  // MX-fp8: whole 256 x 256 tiles (the packed scales come in units of 128 rows and have no notion of a partial one).  K in whole 128-byte K-tiles.
   const int mn_step = dtype == GMD_DT_MXFP8 ? BM : 8;
   if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || (m % mn_step) || (n % mn_step)) return GMD_ERR_BADPARAM;
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return GMD_ERR_BADPARAM;
@@ -1797,7 +1817,7 @@ int gmd_gemm_launch_mx(const void* a, const void* b, const void* scale_a_packed,
 }
 
 int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int rows, int k, void* hip_stream) {
-  if (!scales_row_major || !packed || rows <= 0 || k <= 0 || (rows % 64) || (k % 128) || ((uintptr_t)packed & 3)) return GMD_ERR_BADPARAM;
+  if (!scales_row_major || !packed || rows <= 0 || k <= 0 || (rows % 128) || (k % 128) || ((uintptr_t)packed & 3)) return GMD_ERR_BADPARAM;
   pack_scales_kernel<<<1024, 256, 0, (hipStream_t)hip_stream>>>((const uint8_t*)scales_row_major, (uint32_t*)packed, rows, k / 32);
   GMD_HIP(hipGetLastError());
   return GMD_OK;

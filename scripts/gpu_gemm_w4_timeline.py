@@ -29,8 +29,14 @@ for dtype in os.environ.get("GEMM_TL_DTYPES", "bf16,fp8").split(","):
     b = torch.randn(s, s, device=dev)
     a, b = (a.bfloat16(), b.bfloat16()) if dtype == "bf16" else (a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn))
     c = torch.empty(s, s, dtype=torch.bfloat16, device=dev)
+    kw = {}
+    if dtype == "mxfp8":
+        sc = torch.randint(124, 131, (s, s // 32), dtype=torch.uint8, device=dev)
+        pk = torch.empty_like(sc)
+        diag.mx_pack_scales(sc.data_ptr(), pk.data_ptr(), s, s, stream)
+        kw = {"scale_a": pk.data_ptr(), "scale_b": pk.data_ptr()}
     diag.gemm_set_variant(int(os.environ.get("GEMM_TL_VARIANT", "51")))
-    launch = lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), s, s, s, stream)
+    launch = lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), s, s, s, stream, **kw)
     for _ in range(5):
         launch()
     torch.cuda.synchronize()

@@ -340,7 +340,7 @@ def test_gemm_rejects_shapes_the_tiling_cannot_cover(diag, dev):
             diag.gemm_launch("bf16", x.data_ptr(), x.data_ptr(), x.data_ptr(), m, n, k, _stream())
     with pytest.raises(diag.DiagError):
         diag.gemm_launch("fp8", x.data_ptr(), x.data_ptr(), x.data_ptr(), 512, 512, 192, _stream())
-    with pytest.raises(diag.DiagError):  # MX-fp8: whole tiles only (the packed scales come in units of 64 rows)
+    with pytest.raises(diag.DiagError):  # MX-fp8: whole tiles only (the packed scales come in units of 128 rows)
         diag.gemm_launch("mxfp8", x.data_ptr(), x.data_ptr(), x.data_ptr(), 264, 512, 512, _stream(), scale_a=x.data_ptr(),
                          scale_b=x.data_ptr())
 
