@@ -950,7 +950,7 @@ __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x
 #define W4_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 // ABL (ablation builds only; results are wrong, timing is the point): 1 no fragment reads, 2 no DMA, 4 no MFMAs,
-// 16 clock stamps, 32 no barriers, 128 (with 16) the stamps say when and on which CU instead of how long.  EPI: see store_acc.
+// 16 clock stamps, 32 no barriers, 64 (with 16) the stamps split the prologue, 128 (with 16) the stamps say when and on which CU instead of how long.  EPI: see store_acc.
 // STREAM: one workgroup per CU walks the tiles j, j + G/8, ... of its XCD's chunk without draining the ring: the
 // half-tiles a tile's last pair issues and reads beyond its end are the first ones of the next tile (they land in
 // the slots and registers that tile's first pair expects), so a tile boundary is the epilogue and nothing else.
@@ -1128,6 +1128,13 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   int sAL = 0, sAH = 0, sBX = 0, sBY = 0;  // MX: the scale dword that goes with each fragment set
 
   // Prologue: half-tiles 0..7 (K-tiles 0 and 1) in flight, 0..3 landed (phases 0 and 1 read 2 and 3), 0 and 1 in registers.
+#ifdef GMD_GEMM_ABLATE
+  unsigned long long stamp_pa = 0, stamp_pb = 0, stamp_pc = 0;  // ABL 64: before the first DMA, behind the last, data landed
+  if constexpr ((ABL & 80) == 80) {
+    asm volatile("s_nop 0" ::"v"(off_imm[0]), "v"(a_off[0]), "s"(gA), "s"(gB));
+    stamp_pa = __builtin_amdgcn_s_memtime();
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const bool zero = GEN && (j >> 2) >= ktiles;  // a single K-tile: its partner is the zero one
@@ -1137,7 +1144,13 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     constexpr_dma4(base, j, (j & 3) == 1 || (j & 3) == 2, zero);
     if constexpr (kMx) dma_scale(j & 3, kt, j, sc_a, sc_b);
   }
+#ifdef GMD_GEMM_ABLATE
+  if constexpr ((ABL & 80) == 80) stamp_pb = __builtin_amdgcn_s_memtime();
+#endif
   wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
+#ifdef GMD_GEMM_ABLATE
+  if constexpr ((ABL & 80) == 80) stamp_pc = __builtin_amdgcn_s_memtime();
+#endif
   GMD_PHASE_FENCE();
 #pragma unroll
   for (int j = 0; j < 8; j++) read_one(aL, 0, true, j);
@@ -1363,6 +1376,13 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
         g_gemm_timeline[4 * wgid + 1] = r4;
         g_gemm_timeline[4 * wgid + 2] = ((unsigned long long)xcc << 32) | hw;
         g_gemm_timeline[4 * wgid + 3] = s4 - stamp_t0;
+      }
+    } else if constexpr ((ABL & 64) != 0) {
+      if (threadIdx.x == 0 && wgid < kStampSlots) {  // the prologue in four steps
+        g_gemm_timeline[4 * wgid] = stamp_pa - stamp_t0;
+        g_gemm_timeline[4 * wgid + 1] = stamp_pb - stamp_t0;
+        g_gemm_timeline[4 * wgid + 2] = stamp_pc - stamp_t0;
+        g_gemm_timeline[4 * wgid + 3] = stamp_s1 - stamp_t0;
       }
     } else if (threadIdx.x == 0 && wgid < kStampSlots) {
       g_gemm_timeline[4 * wgid] = stamp_s1 - stamp_t0;
@@ -1701,6 +1721,7 @@ int launch_gemm_t(const GemmArgs& g) {
       case 69: return launch_lds(gemm_w4_kernel<DT, 16 | (2 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 4 apart
       case 70: return launch_lds(gemm_w4_kernel<DT, 16 | (3 << 8)>, grid, kThreadsW4, w4_lds, g);  // pieces 5 apart from 12
       case 71: return launch_lds(gemm_w4_kernel<DT, 16 | (4 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 3 apart
+      case 76: return launch_lds(gemm_w4_kernel<DT, 16 | 64>, grid, kThreadsW4, w4_lds, g);  // stamps: the prologue in four steps
       case 75: return launch_lds(gemm_w4_kernel<DT, 16 | 128>, grid, kThreadsW4, w4_lds, g);  // stamps: when and on which CU
       case 73: return launch_lds(gemm_w4_kernel<DT, 16, 2>, grid, kThreadsW4, w4_lds, g);  // stamps, cached stores
       case 74: return launch_lds(gemm_w4_kernel<DT, 16, 0>, grid, kThreadsW4, w4_lds, g);  // stamps, narrow cached stores
@@ -1743,7 +1764,7 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 75)) {
+      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 76)) {
     g_gemm_variant = variant;
     return GMD_OK;
   }
