@@ -1,0 +1,51 @@
+"""What the general instantiation of the four-wave GEMM costs: shapes with partial tiles and odd K-tile counts next to
+the nearest full-tile, even-count shape, bf16 and fp8, with torch.matmul (hipBLASLt) for bf16.  Writes
+gpurun_out/gemm_shapes.json."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from k8s_gpu_monitor_amd.ops import diag  # noqa: E402
+
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream().cuda_stream
+out = []
+
+
+def timed(fn, n=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n)
+    return best
+
+
+for dtype in ("bf16", "fp8"):
+    kt = 64 if dtype == "bf16" else 128
+    for (m, n, k) in [(8192, 8192, 8192), (8192, 8192, 8192 + kt), (8200, 8200, 8192), (8000, 8000, 8192), (4000, 4104, 4096 + kt),
+                      (1000, 520, 5 * kt)]:
+        a = torch.randn(m, k, device=dev)
+        b = torch.randn(n, k, device=dev)
+        a, b = (a.bfloat16(), b.bfloat16()) if dtype == "bf16" else (a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn))
+        c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        ms = timed(lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, stream))
+        row = {"dtype": dtype, "m": m, "n": n, "k": k, "ms": round(ms, 4), "tflops": round(2.0 * m * n * k / ms / 1e9, 1)}
+        if dtype == "bf16":
+            bt = b.t()
+            tms = timed(lambda: torch.matmul(a, bt, out=c))
+            row.update({"torch_ms": round(tms, 4), "torch_tflops": round(2.0 * m * n * k / tms / 1e9, 1)})
+        print(row, flush=True)
+        out.append(row)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/gemm_shapes.json", "w"), indent=1)
