@@ -1805,8 +1805,14 @@ static int gemm_launch_checked(int dtype, const void* a, const void* b, const vo
   // bf16 and fp8: M and N in multiples of 8 (a lane stores eight columns; rows are dealt to lanes in groups of eight);
   // MX-fp8: whole 256 x 256 tiles (the packed scales come in units of 128 rows and have no notion of a partial one).  K in whole 128-byte K-tiles.
   const int mn_step = dtype == GMD_DT_MXFP8 ? BM : 8;
-  if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || (m % mn_step) || (n % mn_step)) return GMD_ERR_BADPARAM;
-  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return GMD_ERR_BADPARAM;
+  if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || (m % mn_step) || (n % mn_step) || (k % (dtype == GMD_DT_BF16 ? 64 : 128))) {
+    gmd::set_error("GEMM shape: M and N in multiples of 8 (bf16, fp8) or 256 (MX-fp8), K in multiples of 64 (bf16) or 128 (fp8, MX-fp8)");
+    return GMD_ERR_BADPARAM;
+  }
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) {
+    gmd::set_error("GEMM operands must be 16-byte aligned");
+    return GMD_ERR_BADPARAM;
+  }
   GemmArgs g{a, b, c, m, n, 0, (const uint32_t*)sa, (const uint32_t*)sb, (hipStream_t)hip_stream};
   switch (dtype) {
     case GMD_DT_BF16:
@@ -1850,7 +1856,10 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
   const bool fp8 = dtype == GMD_DT_FP8 || dtype == GMD_DT_MXFP8;
   const bool mx = dtype == GMD_DT_MXFP8;
   if (dtype != GMD_DT_BF16 && !fp8) return GMD_ERR_BADPARAM;
-  if (m <= 0 || n <= 0 || k <= 0 || (m % (mx ? BM : 8)) || (n % (mx ? BN : 8)) || (k % (fp8 ? 128 : 64))) return GMD_ERR_BADPARAM;
+  if (m <= 0 || n <= 0 || k <= 0 || (m % (mx ? BM : 8)) || (n % (mx ? BN : 8)) || (k % (fp8 ? 128 : 64))) {
+    gmd::set_error("GEMM shape: M and N in multiples of 8 (bf16, fp8) or 256 (MX-fp8), K in multiples of 64 (bf16) or 128 (fp8, MX-fp8)");
+    return GMD_ERR_BADPARAM;
+  }
   GMD_HIP(hipSetDevice(device));
   const size_t esz = fp8 ? 1 : 2;
   gmd::DeviceBuffer a, b, c, sums, sa_nat, sb_nat, sa_pk, sb_pk, refs;
