@@ -1176,6 +1176,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // flag was tried: four s_cmp + s_cbranch per phase, never taken before the last pair, cost 10 % of the K loop.
   // So was pointing the first half of the surplus at the first K-tile of the tile that follows on this XCD (ids + 32), to
   // have it in L2 for that workgroup's prologue: the prologue stayed at 3.2-3.4 k cycles and the K loop grew by 2.4 k.
+  // And so was running the surplus DMA with no lane enabled (EXEC = 0: the instruction keeps its place in the vmcnt queue,
+  // scripts/probes/exec0_vmcnt_probe.hip, and moves no data): the two EXEC writes per piece cost the same 10 %.
   const int last_kt = (int)(row_bytes / BKB) - 1;
   constexpr int kStoresW4 = EPI ? 32 : 64;  // store instructions per wave of one tile (store_acc<8>)
   static_assert(!STREAM || kPerHalf * (kAheadW4 - 4) + kStoresW4 <= 63, "vmcnt is a six-bit counter");

@@ -23,7 +23,7 @@ stream = torch.cuda.current_stream().cuda_stream
 out = {"numerics": [], "timing": []}
 VARIANTS = tuple(int(x) for x in os.environ.get("GEMM_AB_VARIANTS", "0,1,2,3,4,5").split(","))
 SIZES = tuple(int(x) for x in os.environ.get("GEMM_AB_SIZES", "4096,8192,16384").split(","))
-PERSISTENT = tuple(int(x) for x in os.environ.get("GEMM_AB_PERSISTENT", "3").split(","))
+PERSISTENT = tuple(int(x) for x in os.environ.get("GEMM_AB_PERSISTENT", "3").split(",") if x)
 
 
 class Case:
