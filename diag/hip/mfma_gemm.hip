@@ -950,6 +950,7 @@ __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x
 #define W4_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 // ABL (ablation builds only; results are wrong, timing is the point): 1 no fragment reads, 2 no DMA, 4 no MFMAs,
+// 8 no M0 writes (what the one per half-tile costs),
 // 16 clock stamps, 32 no barriers, 64 (with 16) the stamps split the prologue, 128 (with 16) the stamps say when and on which CU instead of how long.  EPI: see store_acc.
 // STREAM: one workgroup per CU walks the tiles j, j + G/8, ... of its XCD's chunk without draining the ring: the
 // half-tiles a tile's last pair issues and reads beyond its end are the first ones of the next tile (they land in
@@ -1074,7 +1075,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     }
     // Every statement names M0 as clobbered: pieces 1..3 rely on the M0 that piece 0 wrote, and the clobber is what
     // keeps the compiler from parking an M0 write of its own between them.
-    if constexpr (i == 0)
+    if constexpr (i == 0 && !(ABL & 8))
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(0), "s"(lds)
                    : "memory", "m0");
     else
@@ -1723,6 +1724,7 @@ int launch_gemm_t(const GemmArgs& g) {
       case 69: return launch_lds(gemm_w4_kernel<DT, 16 | (2 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 4 apart
       case 70: return launch_lds(gemm_w4_kernel<DT, 16 | (3 << 8)>, grid, kThreadsW4, w4_lds, g);  // pieces 5 apart from 12
       case 71: return launch_lds(gemm_w4_kernel<DT, 16 | (4 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 3 apart
+      case 77: return launch_lds(gemm_w4_kernel<DT, 16 | 8>, grid, kThreadsW4, w4_lds, g);  // stamps; M0 is never written (every half-tile lands in one slot)
       case 76: return launch_lds(gemm_w4_kernel<DT, 16 | 64>, grid, kThreadsW4, w4_lds, g);  // stamps: the prologue in four steps
       case 75: return launch_lds(gemm_w4_kernel<DT, 16 | 128>, grid, kThreadsW4, w4_lds, g);  // stamps: when and on which CU
       case 73: return launch_lds(gemm_w4_kernel<DT, 16, 2>, grid, kThreadsW4, w4_lds, g);  // stamps, cached stores
@@ -1766,7 +1768,7 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 76)) {
+      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 77)) {
     g_gemm_variant = variant;
     return GMD_OK;
   }
