@@ -369,6 +369,30 @@ def test_link_test_without_a_gpu_is_an_error_not_a_crash():
         diag.link_test("uni", devices=[0])
 
 
+def test_gemm_shape_rules_are_checked_before_anything_touches_a_device():
+    """The GEMM entry points refuse a shape they cannot run before any HIP call, with a message that says what the shape
+    must be: M and N in multiples of 8 for bf16 and fp8 (256 for MX-fp8, whose packed scales know no partial tile), K in
+    whole 128-byte K-tiles, operands 16-byte aligned.  No GPU is needed to see that."""
+    from k8s_gpu_monitor_amd.ops import diag
+    p = 0x10000  # never dereferenced: the shape is refused first
+    for dtype, m, n, k in [("bf16", 500, 512, 512), ("bf16", 512, 508, 512), ("bf16", 512, 512, 96), ("bf16", 0, 512, 512),
+                           ("fp8", 512, 512, 192), ("fp8", 12, 512, 256)]:
+        with pytest.raises(diag.DiagError) as e:
+            diag.gemm_launch(dtype, p, p, p, m, n, k)
+        assert "multiples of 8" in str(e.value), (dtype, m, n, k)
+    with pytest.raises(diag.DiagError) as e:
+        diag.gemm_launch("mxfp8", p, p, p, 264, 512, 512, scale_a=p, scale_b=p)
+    assert "256 (MX-fp8)" in str(e.value)
+    with pytest.raises(diag.DiagError) as e:
+        diag.gemm_launch("bf16", p + 8, p, p, 512, 512, 512)
+    assert "16-byte aligned" in str(e.value)
+    with pytest.raises(diag.DiagError):
+        diag.mx_pack_scales(p, p, 192, 512)   # rows in multiples of 128
+    with pytest.raises(diag.DiagError) as e:
+        diag.gemm_stress("bf16", 1000, 1001, 512, seconds=0.01)
+    assert "multiples of 8" in str(e.value)
+
+
 def test_gpumon_diag_takes_every_documented_value_flag():
     """Every flag of the usage text that carries a value is parsed as such (a flag missing from the parser's list
     turns its value into an 'unexpected argument').  Without a GPU the commands then stop at the device, not at
