@@ -1120,11 +1120,17 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     else f[j >> 1].lo = v;
   };
 
+  // MX-fp8 clears the accumulators in the shadow of the prologue's DMA issue (eight of them behind every half-tile, held
+  // there by an empty asm): issue is bound by the address path at ~60 cycles per instruction and per wave, and the 256
+  // v_accvgpr_write otherwise sit between the wait for the first data and the first MFMA (1 k cycles of a 148 k-cycle
+  // tile).  For bf16 and fp8 the compiler's own placement costs nothing measurable and the interleaving slows the issue.
   f32x4 acc[8][8];
+  if constexpr (!kMx) {
 #pragma unroll
-  for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-    for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   i32x8 aL[4], aH[4], bX[4], bY[4];
   int sAL = 0, sAH = 0, sBX = 0, sBY = 0;  // MX: the scale dword that goes with each fragment set
 
@@ -1144,6 +1150,13 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     if constexpr (GEN) base = zero ? zero_base : base;
     constexpr_dma4(base, j, (j & 3) == 1 || (j & 3) == 2, zero);
     if constexpr (kMx) dma_scale(j & 3, kt, j, sc_a, sc_b);
+    if constexpr (kMx) {
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+a"(acc[j][t]));
+      }
+    }
   }
 #ifdef GMD_GEMM_ABLATE
   if constexpr ((ABL & 80) == 80) stamp_pb = __builtin_amdgcn_s_memtime();
@@ -1287,6 +1300,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   };
 
   const int npairs = ((int)(row_bytes / BKB) + (GEN ? 1 : 0)) >> 1;
+  // The launcher sends no shape with fewer than one pair.  Saying so removes the path round the K loop, on which the
+  // accumulators are constants, and with it the copies that merge the two paths at the top of the block behind the loop:
+  // those read accumulator registers ahead of the drain.
+  __builtin_assume(npairs > 0);
   bool after_epilogue = false;
   for (;;) {
     for (int it = 0; it < npairs; it++) {
@@ -1341,9 +1358,11 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     stamp_s2 = __builtin_amdgcn_s_memtime();
   }
 #endif
-  wait_vmcnt<0>();  // the last pair's surplus DMA must not outlive the workgroup's LDS
-  __builtin_amdgcn_sched_barrier(0);
-  W4_DRAIN();
+  // One statement: the wait for the last pair's surplus DMA (it must not outlive the workgroup's LDS) and the drain of
+  // the matrix pipe, whose result latency the compiler does not know.  The copies out of the accumulators that the
+  // epilogue needs are the compiler's to place; it places them behind the first statement of this block, which is why
+  // the drain is part of that statement (tests/test_diag_codegen.py reads the disassembly and holds it to that).
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 #ifdef GMD_GEMM_ABLATE
   unsigned long long stamp_s3 = 0;
@@ -1358,8 +1377,12 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 #endif
 
   if constexpr (!STREAM) {
-    if constexpr (kRowsDealt && GEN) store_acc_rows_edge<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq, M, N);
-    else if constexpr (kRowsDealt) store_acc_rows<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq);
+    // The lane's position is worked out afresh (two mbcnt): carried over from the top of the kernel it is two registers
+    // that live through the K loop for nothing, and that the register allocator may decide to spill and reload here.
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
+    if constexpr (kRowsDealt && GEN) store_acc_rows_edge<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e, M, N);
+    else if constexpr (kRowsDealt) store_acc_rows<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e);
     else store_acc<8, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
   }
 #ifdef GMD_GEMM_ABLATE
@@ -1368,7 +1391,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     // DMA landed, last store issued.
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long s4 = __builtin_amdgcn_s_memtime();
-    if constexpr (ABL & 128) {
+    if constexpr ((ABL & 192) == 192) {
+      // per wave: ticks from the first instruction to the end of the prologue's wait for data (how far apart the four waves are)
+      if (lane == 0 && wgid < kStampSlots) g_gemm_timeline[4 * wgid + wave] = stamp_pc - stamp_t0;
+    } else if constexpr (ABL & 128) {
       // Where and when the workgroup ran: 100 MHz real-time at its first instruction and behind its last store, and the
       // HW_ID register (CU, shader engine, XCC) of wave 0, to line up the workgroups that followed one another on a CU.
       const unsigned long long r4 = __builtin_amdgcn_s_memrealtime();
@@ -1725,6 +1751,7 @@ int launch_gemm_t(const GemmArgs& g) {
       case 70: return launch_lds(gemm_w4_kernel<DT, 16 | (3 << 8)>, grid, kThreadsW4, w4_lds, g);  // pieces 5 apart from 12
       case 71: return launch_lds(gemm_w4_kernel<DT, 16 | (4 << 8)>, grid, kThreadsW4, w4_lds, g);  // reads 2 apart, pieces 3 apart
       case 77: return launch_lds(gemm_w4_kernel<DT, 16 | 8>, grid, kThreadsW4, w4_lds, g);  // stamps; M0 is never written (every half-tile lands in one slot)
+      case 78: return launch_lds(gemm_w4_kernel<DT, 16 | 64 | 128>, grid, kThreadsW4, w4_lds, g);  // stamps: the prologue's wait, per wave
       case 76: return launch_lds(gemm_w4_kernel<DT, 16 | 64>, grid, kThreadsW4, w4_lds, g);  // stamps: the prologue in four steps
       case 75: return launch_lds(gemm_w4_kernel<DT, 16 | 128>, grid, kThreadsW4, w4_lds, g);  // stamps: when and on which CU
       case 73: return launch_lds(gemm_w4_kernel<DT, 16, 2>, grid, kThreadsW4, w4_lds, g);  // stamps, cached stores
@@ -1768,7 +1795,7 @@ extern "C" {
 int gmd_gemm_set_variant(int variant) {
 #ifdef GMD_GEMM_ABLATE
   if ((variant >= 11 && variant <= 18) || variant == 23 || (variant >= 25 && variant <= 27) || variant == 33 || variant == 34 ||
-      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 77)) {
+      (variant >= 41 && variant <= 46) || variant == 51 || variant == 53 || (variant >= 62 && variant <= 78)) {
     g_gemm_variant = variant;
     return GMD_OK;
   }

@@ -52,6 +52,12 @@ for dtype in os.environ.get("GEMM_TL_DTYPES", "bf16,fp8").split(","):
     assert lib.gmd_gemm_read_timeline(buf, ntiles) == 0
     tl = [(buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]) for i in range(ntiles)]
     med = lambda xs: statistics.median(xs)
+    if os.environ.get("GEMM_TL_VARIANT") == "78":  # per wave: ticks to the end of the prologue's wait for data
+        row = {"dtype": dtype, "size": s, "wave_ticks_median": [med(t[w] for t in tl) for w in range(4)],
+               "spread_median": med(max(t) - min(t) for t in tl)}
+        print(row, flush=True)
+        out.append(row)
+        continue
     if os.environ.get("GEMM_TL_VARIANT") == "76":  # the prologue in four steps (ticks from the first instruction)
         row = {"dtype": dtype, "size": s, "ms_per_launch": round(ms, 4), "before_first_dma": med(t[0] for t in tl),
                "dma_issued": med(t[1] for t in tl), "first_half_tiles_landed": med(t[2] for t in tl), "fragments_read": med(t[3] for t in tl)}
