@@ -1096,26 +1096,41 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   const uint32_t* sc_b = kMx ? scale_base(SB, tn, wc) : nullptr;
   const uint32_t* nsc_a = kMx && has_next ? scale_base(SA, ntm, wr) : sc_a;
   const uint32_t* nsc_b = kMx && has_next ? scale_base(SB, ntn, wc) : sc_b;
+  uint32_t lane_x4 = (uint32_t)lane * 4;
+  asm volatile("" : "+v"(lane_x4));
   auto dma_scale = [&](int kind, int kt, int slot, const uint32_t* sa_base, const uint32_t* sb_base) {
     const uint32_t* src = ((kind == 0 || kind == 3) ? sa_base : sb_base) + ((size_t)(kind >= 2 ? ktiles : 0) + kt) * kScaleUnitDwords;
     const uint32_t lds = (uint32_t)(uintptr_t)(my_scales + slot * 256);
-    const uint32_t* lane_src = src + lane;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(lane_src), "s"(lds) : "memory", "m0");
+    // Wave-uniform, and meant for SGPRs: the distance from the tensor's start goes through readfirstlane (a no-op where the
+    // compiler has followed the uniformity, one VALU instruction where it has not) and back onto the kernel argument.
+    const bool is_a = kind == 0 || kind == 3;
+    const uint32_t dist = __builtin_amdgcn_readfirstlane((uint32_t)((const char*)src - (const char*)(is_a ? SA : SB)));
+    src = (const uint32_t*)((const char*)(is_a ? SA : SB) + dist);
+    asm volatile("" : "+s"(src));
+    // SGPR base + one VGPR offset (4 * lane) that never changes: a per-lane 64-bit address would be a VALU add per unit.
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_x4), "s"(src), "s"(lds) : "memory", "m0");
   };
   auto read_scale = [&](int slot) { return *(const int*)(my_scales + slot * 256 + lane * 4); };
 
   // Fragment read offsets inside a slot (local rows: A wr*64 + fr, B wc*64 + fr).
   const int fr = lane & 15, fq = lane >> 4;
-  int a_off[2], b_off[2];
+  // ds_read's immediate offset is 16 bits and the ring is 128 KiB: slots 4..7 get bases of their own, 64 KiB further
+  // on, that an empty asm makes opaque.  Left to itself the compiler keeps one base and adds 65536 to it in front of the
+  // reads of half the phases: eight VALU adds per pair of K-tiles, each of them an MFMA issue slot with one wave per SIMD.
+  int a_off[2], b_off[2], a_off_far[2], b_off_far[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
     const int ch = ks * 4 + fq;
     a_off[ks] = lds_off<DT>(wr * 64 + fr, ch);
     b_off[ks] = lds_off<DT>(wc * 64 + fr, ch);
+    a_off_far[ks] = a_off[ks] + 4 * kHalfBytes;
+    b_off_far[ks] = b_off[ks] + 4 * kHalfBytes;
+    asm volatile("" : "+v"(a_off_far[ks]), "+v"(b_off_far[ks]));
   }
   // One of the eight 16-byte reads of a half-tile's fragments: block j>>1 (16 rows), half j&1.
   auto read_one = [&](i32x8 (&f)[4], int slot, bool is_a, int j) {
-    const i32x4 v = *(const i32x4*)(smem + slot * kHalfBytes + (is_a ? a_off[j & 1] : b_off[j & 1]) + (j >> 1) * 2048);
+    const int base = slot >= 4 ? (is_a ? a_off_far[j & 1] : b_off_far[j & 1]) : (is_a ? a_off[j & 1] : b_off[j & 1]);
+    const i32x4 v = *(const i32x4*)(smem + (slot & 3) * kHalfBytes + base + (j >> 1) * 2048);
     if (j & 1) f[j >> 1].hi = v;
     else f[j >> 1].lo = v;
   };
