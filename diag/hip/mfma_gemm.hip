@@ -992,8 +992,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   if (STREAM && wgid >= chunk_end) return;  // whole workgroup, before any barrier
   int tm, tn;
   tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
-  const char* gA = A + (size_t)tm * BM * row_bytes;
-  const char* gB = B + (size_t)tn * BN * row_bytes;
+  // Tile bases carry the offset bias of the DMA lanes (see off_imm) from the start, so that no phase has to subtract it.
+  constexpr int kOffBias = 3 * 1024;
+  const char* gA = A + (size_t)tm * BM * row_bytes - kOffBias;
+  const char* gB = B + (size_t)tn * BN * row_bytes - kOffBias;
   // the tile after this one (stream only): where the last pair's surplus half-tiles come from
   bool has_next = false;
   int ntm = tm, ntn = tn;
@@ -1003,8 +1005,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     has_next = STREAM && wgid + tile_step < chunk_end;
     if (has_next) {
       tile_of(wgid + tile_step, tiles_m, tiles_n, &ntm, &ntn);
-      nA = A + (size_t)ntm * BM * row_bytes;
-      nB = B + (size_t)ntn * BN * row_bytes;
+      nA = A + (size_t)ntm * BM * row_bytes - kOffBias;
+      nB = B + (size_t)ntn * BN * row_bytes - kOffBias;
     }
   };
   look_ahead();
@@ -1041,9 +1043,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   char* const my_pieces = smem + wave * 4096;
 
   // kind: 0 A-lo, 1 B-lo, 2 B-hi, 3 A-hi.  Wave-uniform part of the source address of one half-tile, kept in SGPRs.
-  constexpr int kOffBias = 3 * 1024;
   auto piece_base = [&](int kind, int kt, const char* pa, const char* pb) {
-    const char* base = ((kind == 0 || kind == 3) ? pa : pb) + ((kind >= 2) ? hi_off : 0) + (size_t)kt * BKB - kOffBias;
+    const char* base = ((kind == 0 || kind == 3) ? pa : pb) + ((kind >= 2) ? hi_off : 0) + (size_t)kt * BKB;
     asm volatile("" : "+s"(base));
     return base;
   };
@@ -1073,13 +1074,15 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
       if (is_b) o = i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3;
       if (zero) o = off_zero;
     }
-    // Every statement names M0 as clobbered: pieces 1..3 rely on the M0 that piece 0 wrote, and the clobber is what
-    // keeps the compiler from parking an M0 write of its own between them.
+    // Only piece 0 names M0 as clobbered.  Pieces 1..3 rely on the M0 it wrote and say nothing about it: named there too,
+    // the clobber makes the hazard recognizer put a wait state between two pieces that are only two MFMAs apart (24 s_nop
+    // per pair of K-tiles), and nothing the compiler generates in this loop writes M0 (scripts/check_gemm_codegen.py counts
+    // the M0 writes between the first and the last MFMA of every instantiation).
     if constexpr (i == 0 && !(ABL & 8))
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(0), "s"(lds)
                    : "memory", "m0");
     else
-      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(i * 1024) : "memory", "m0");
+      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(i * 1024) : "memory");
   };
   auto constexpr_dma4 = [&](const char* base, int slot, bool is_b, bool zero) {
     dma(base, slot, std::integral_constant<int, 0>{}, is_b, zero);

@@ -3,7 +3,8 @@
 express: the MFMAs are inline asm, so the compiler knows nothing of their result latency, and the copies out of the
 accumulator registers that the epilogue needs (v_accvgpr_read) are the compiler's to place.  Every such copy must have
 a matrix-pipe drain (s_nop 15) between it and the last MFMA before it in program order; the K loop must hold no
-scratch access and no s_waitcnt vmcnt that the source did not write (a spill reload there would drain the DMA queue).
+scratch access (a spill reload there would drain the DMA queue) and no write to M0 between the four LDS-DMA pieces of
+a half-tile (only the first of them tells the compiler about M0).
 
 usage: check_gemm_codegen.py [lib.so]     exit status 0 = all kernels pass; prints one line per kernel
 """
@@ -56,6 +57,18 @@ def check(name, ins):
     loop = ins[mfma[0]:mfma[-1] + 1]
     if any(l.startswith("scratch_") for l in loop):
         problems.append("scratch access between the first and the last MFMA")
+    # M0 is the LDS base of the LDS-DMA pieces: one write per half-tile (the s_mov_b32 of piece 0) and per MX scale unit,
+    # each followed by the loads that use it; pieces 1..3 do not declare M0, so a write of the compiler's own between a
+    # piece 0 and its piece 3 would send them elsewhere.
+    dma = [i for i, l in enumerate(loop) if l.startswith("global_load_lds_dwordx4")]
+    m0 = [i for i, l in enumerate(loop) if re.match(r"s_\w+ m0\b", l)]
+    if len(dma) % 4:
+        problems.append("LDS-DMA pieces do not come in fours")
+    for g in range(0, len(dma) - 3, 4):
+        inside = [i for i in m0 if dma[g] < i < dma[g + 3]]
+        if inside:
+            problems.append(f"M0 written between the pieces of one half-tile (instruction {inside[0]} of the loop)")
+            break
     return problems
 
 
