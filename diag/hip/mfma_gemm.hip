@@ -216,7 +216,7 @@ __device__ __forceinline__ void store_acc_rows_edge(const f32x4 (&acc)[8][8], __
 
 // What the LDS-DMA of a K-tile beyond the last one reads when the K-tile count is odd (the pipelines walk K-tiles in
 // pairs): zeros for both operands, so that the pair's second half adds nothing.
-__device__ uint4 g_gemm_zero_slab[256];
+__device__ uint4 g_gemm_zero_slab[264];  // 4 KiB + 128 B: the odd K-tile of a pair is read 128 bytes further on
 
 template <int DT>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restrict__ A, const char* __restrict__ B,
@@ -1065,10 +1065,15 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   const uint32_t off_zero = (uint32_t)(kOffBias + lane * 16);
   const char* const zero_base = (const char*)g_gemm_zero_slab - kOffBias;
   // `zero`: GEN only, wave-uniform: this half-tile is the zero K-tile.  `is_b`: a compile-time constant at every call.
+  // PAR: the K-tile's parity.  The two K-tiles of a pair share their four bases (one per kind): the odd one is the same
+  // base read 128 bytes further on, through the immediate, with 128 taken off M0 to leave the LDS side where it was.
+  // One scalar 64-bit add per kind and PAIR instead of one per half-tile: with one wave per SIMD scalar instructions
+  // between the MFMAs are not free either (seven add pairs fewer per pair of K-tiles were 3.8 k cycles per tile).
   auto dma = [my_pieces, o0 = off_imm[0], o1 = off_imm[1], o2 = off_imm[2], o3 = off_imm[3], b0 = off_imm_b[0], b1 = off_imm_b[1],
-              b2 = off_imm_b[2], b3 = off_imm_b[3], off_zero](const char* base, int slot, auto I, bool is_b, bool zero) {
+              b2 = off_imm_b[2], b3 = off_imm_b[3], off_zero](const char* base, int slot, auto I, auto PAR, bool is_b, bool zero) {
     constexpr int i = decltype(I)::value;
-    const uint32_t lds = (uint32_t)(uintptr_t)(my_pieces + slot * kHalfBytes);
+    constexpr int kOdd = decltype(PAR)::value * BKB;
+    const uint32_t lds = (uint32_t)(uintptr_t)(my_pieces + slot * kHalfBytes) - kOdd;
     uint32_t o = i == 0 ? o0 : i == 1 ? o1 : i == 2 ? o2 : o3;
     if constexpr (GEN) {
       if (is_b) o = i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3;
@@ -1079,16 +1084,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     // per pair of K-tiles), and nothing the compiler generates in this loop writes M0 (scripts/check_gemm_codegen.py counts
     // the M0 writes between the first and the last MFMA of every instantiation).
     if constexpr (i == 0 && !(ABL & 8))
-      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(0), "s"(lds)
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(kOdd), "s"(lds)
                    : "memory", "m0");
     else
-      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(i * 1024) : "memory");
-  };
-  auto constexpr_dma4 = [&](const char* base, int slot, bool is_b, bool zero) {
-    dma(base, slot, std::integral_constant<int, 0>{}, is_b, zero);
-    dma(base, slot, std::integral_constant<int, 1>{}, is_b, zero);
-    dma(base, slot, std::integral_constant<int, 2>{}, is_b, zero);
-    dma(base, slot, std::integral_constant<int, 3>{}, is_b, zero);
+      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(i * 1024 + kOdd) : "memory");
   };
   // MX scales: the packed unit (256 B: 64 rows x 4 blocks of one K-tile) that belongs to a half-tile travels with
   // it, by one 4-byte-per-lane LDS-DMA into this wave's own slot of a small ring behind the operand ring.
@@ -1160,14 +1159,43 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     stamp_pa = __builtin_amdgcn_s_memtime();
   }
 #endif
+  // What the DMA of one pair of K-tiles needs, worked out once per pair (fetch_pair): the four bases at the pair's even
+  // K-tile, whether its odd K-tile is the zero one (GEN, odd count), and the MX scale tensors and K-tile index.
+  const int last_kt = (int)(row_bytes / BKB) - 1;
+  const char* pair_base[4];
+  bool pair_zero_odd = false;
+  int pair_kt = 0;
+  const uint32_t* pair_sa = sc_a;
+  const uint32_t* pair_sb = sc_b;
+  auto fetch_pair = [&](int bk) {  // bk: the pair's even K-tile
+    const char* pa = gA;
+    const char* pb = gB;
+    pair_sa = sc_a, pair_sb = sc_b;
+    if (bk > last_kt) {  // beyond the tile: the next tile's first pair (stream), or the last pair again, into slots nobody reads
+      if (has_next) {
+        bk -= last_kt + 1;
+        pa = nA, pb = nB, pair_sa = nsc_a, pair_sb = nsc_b;
+      } else {
+        bk = GEN ? (last_kt & ~1) : last_kt - 1;
+      }
+    }
+    pair_zero_odd = GEN && bk + 1 > last_kt;
+    pair_kt = bk;
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const bool zero = GEN && (j >> 2) >= ktiles;  // a single K-tile: its partner is the zero one
-    const int kt = zero ? 0 : j >> 2;
-    const char* base = piece_base(j & 3, kt, gA, gB);
+    for (int kind = 0; kind < 4; kind++) pair_base[kind] = piece_base(kind, bk, pa, pb);
+  };
+  // One half-tile's DMA outside the K loop's interleaving (the prologue).
+  auto issue_half = [&](auto J) {
+    constexpr int j = decltype(J)::value, kind = j & 3;
+    using Par = std::integral_constant<int, (j >> 2)>;
+    const bool zero = GEN && Par::value == 1 && pair_zero_odd;
+    const char* base = pair_base[kind];
     if constexpr (GEN) base = zero ? zero_base : base;
-    constexpr_dma4(base, j, (j & 3) == 1 || (j & 3) == 2, zero);
-    if constexpr (kMx) dma_scale(j & 3, kt, j, sc_a, sc_b);
+    dma(base, j, std::integral_constant<int, 0>{}, Par{}, kind == 1 || kind == 2, zero);
+    dma(base, j, std::integral_constant<int, 1>{}, Par{}, kind == 1 || kind == 2, zero);
+    dma(base, j, std::integral_constant<int, 2>{}, Par{}, kind == 1 || kind == 2, zero);
+    dma(base, j, std::integral_constant<int, 3>{}, Par{}, kind == 1 || kind == 2, zero);
+    if constexpr (kMx) dma_scale(kind, min(pair_kt + Par::value, last_kt), j, pair_sa, pair_sb);
     if constexpr (kMx) {
 #pragma unroll
       for (int t = 0; t < 8; t++) {
@@ -1175,7 +1203,16 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
         asm volatile("" : "+a"(acc[j][t]));
       }
     }
-  }
+  };
+  fetch_pair(0);
+  issue_half(std::integral_constant<int, 0>{});
+  issue_half(std::integral_constant<int, 1>{});
+  issue_half(std::integral_constant<int, 2>{});
+  issue_half(std::integral_constant<int, 3>{});
+  issue_half(std::integral_constant<int, 4>{});
+  issue_half(std::integral_constant<int, 5>{});
+  issue_half(std::integral_constant<int, 6>{});
+  issue_half(std::integral_constant<int, 7>{});
 #ifdef GMD_GEMM_ABLATE
   if constexpr ((ABL & 80) == 80) stamp_pb = __builtin_amdgcn_s_memtime();
 #endif
@@ -1210,7 +1247,6 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // have it in L2 for that workgroup's prologue: the prologue stayed at 3.2-3.4 k cycles and the K loop grew by 2.4 k.
   // And so was running the surplus DMA with no lane enabled (EXEC = 0: the instruction keeps its place in the vmcnt queue,
   // scripts/probes/exec0_vmcnt_probe.hip, and moves no data): the two EXEC writes per piece cost the same 10 %.
-  const int last_kt = (int)(row_bytes / BKB) - 1;
   constexpr int kStoresW4 = EPI ? 32 : 64;  // store instructions per wave of one tile (store_acc<8>)
   static_assert(!STREAM || kPerHalf * (kAheadW4 - 4) + kStoresW4 <= 63, "vmcnt is a six-bit counter");
   auto phase = [&](auto PH, int kt0, bool after_epilogue) {
@@ -1223,26 +1259,17 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     constexpr int R = P + 2, rk = R & 3, rpar = (R >> 2) & 1;
     i32x8(&Rf)[4] = rk == 0 ? aL : rk == 3 ? aH : (rk == 1) == (rpar == 0) ? bX : bY;
     constexpr int rslot = R & 7;
-    // issued during this phase: half-tile P+8, into the slot half-tile P leaves.  Beyond the end of the tile that is
-    // the next tile's K-tile 0 or 1 (stream, with a successor) or the last K-tile again (slots nobody reads any more).
-    int ikt = kt0 + 2 + par;
-    const char* pa = gA;
-    const char* pb = gB;
-    const uint32_t* psa = sc_a;
-    const uint32_t* psb = sc_b;
-    // GEN, odd K-tile count: the K-tile right behind the last one is the zero K-tile, for A and B alike
-    const bool zero = GEN && ikt == last_kt + 1 && !(last_kt & 1);
-    if (ikt > last_kt) {
-      if (has_next) {
-        ikt -= last_kt + 1;
-        pa = nA, pb = nB, psa = nsc_a, psb = nsc_b;
-      } else {
-        ikt = last_kt;
-      }
-    }
-    const char* base = piece_base(p, ikt, pa, pb);
+    // issued during this phase: half-tile P+8, into the slot half-tile P leaves, from the bases fetch_pair(kt0 + 2) set
+    // (beyond the end of the tile: the next tile's first pair (stream, with a successor) or the last pair again).
+    // GEN, odd K-tile count: the K-tile right behind the last one is the zero K-tile, for A and B alike.
+    const bool zero = GEN && par == 1 && pair_zero_odd;
+    const char* base = pair_base[p];
     if constexpr (GEN) base = zero ? zero_base : base;
     constexpr bool is_b = p == 1 || p == 2;
+    using Par = std::integral_constant<int, par>;
+    const uint32_t* psa = pair_sa;
+    const uint32_t* psb = pair_sb;
+    const int ikt = min(pair_kt + par, last_kt);  // MX: the scale unit's K-tile
     int& sAf = (p < 2) ? sAL : sAH;
     int& sBf = (p == 0 || p == 3) ? (par ? sBY : sBX) : (par ? sBX : sBY);
     int& sRf = rk == 0 ? sAL : rk == 3 ? sAH : (rk == 1) == (rpar == 0) ? sBX : sBY;
@@ -1261,10 +1288,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
           if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i);
         } else if (i < 12) {
           if constexpr (!(ABL & 2)) {
-            if (i == 8) dma(base, P, std::integral_constant<int, 0>{}, is_b, zero);
-            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{}, is_b, zero);
-            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{}, is_b, zero);
-            else dma(base, P, std::integral_constant<int, 3>{}, is_b, zero);
+            if (i == 8) dma(base, P, std::integral_constant<int, 0>{}, Par{}, is_b, zero);
+            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero);
+            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero);
+            else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero);
           }
         } else if (i == 12) {
           if constexpr (!(ABL & 2)) dma_scale(p, ikt, P, psa, psb);
@@ -1287,10 +1314,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
         if (i >= kDma0 && (i - kDma0) % kDmaStep == 0 && (i - kDma0) / kDmaStep < 4) {
           if constexpr (!(ABL & 2)) {
             const int q = (i - kDma0) / kDmaStep;
-            if (q == 0) dma(base, P, std::integral_constant<int, 0>{}, is_b, zero);
-            else if (q == 1) dma(base, P, std::integral_constant<int, 1>{}, is_b, zero);
-            else if (q == 2) dma(base, P, std::integral_constant<int, 2>{}, is_b, zero);
-            else dma(base, P, std::integral_constant<int, 3>{}, is_b, zero);
+            if (q == 0) dma(base, P, std::integral_constant<int, 0>{}, Par{}, is_b, zero);
+            else if (q == 1) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero);
+            else if (q == 2) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero);
+            else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero);
           }
         }
         if (i <= (kDma0 + 3 * kDmaStep > 7 * kReadStep ? kDma0 + 3 * kDmaStep : 7 * kReadStep)) __builtin_amdgcn_sched_barrier(0);
@@ -1327,6 +1354,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     for (int it = 0; it < npairs; it++) {
       const int kt0 = 2 * it;
       const bool ae = after_epilogue && it == 0;
+      fetch_pair(kt0 + 2);
       phase(std::integral_constant<int, 0>{}, kt0, ae);
       phase(std::integral_constant<int, 1>{}, kt0, ae);
       phase(std::integral_constant<int, 2>{}, kt0, ae);
