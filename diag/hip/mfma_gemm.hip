@@ -948,6 +948,9 @@ __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x
   }
 }
 #define W4_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+// s_waitcnt lgkmcnt(0) as the builtin (vmcnt and expcnt fields at their maxima: not waited for): unlike the same
+// instruction in inline asm the compiler's own wait-count pass takes it into account.
+__device__ __forceinline__ void w4_wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
 // ABL (ablation builds only; results are wrong, timing is the point): 1 no fragment reads, 2 no DMA, 4 no MFMAs,
 // 8 no M0 writes (what the one per half-tile costs),
@@ -1274,6 +1277,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     int& sBf = (p == 0 || p == 3) ? (par ? sBY : sBX) : (par ? sBX : sBY);
     int& sRf = rk == 0 ? sAL : rk == 3 ? sAH : (rk == 1) == (rpar == 0) ? sBX : sBY;
     constexpr int NM = DT == GMD_DT_BF16 ? 32 : DT == GMD_DT_FP8 ? 64 : 16;
+    // The fragments this phase multiplies were read at least 24 MFMAs ago.  One wait the compiler can see says so at the
+    // top of the phase (an even phase starts behind the odd one's wait before the barrier); without it the compiler
+    // counts the reads down with four or five s_waitcnt of its own between the MFMAs of every phase.
+    if constexpr (P & 1) w4_wait_lds();
 #pragma unroll
     for (int i = 0; i < NM; i++) {
       const int sub = i >> 4, mb = (i >> 2) & 3, nb = i & 3;
@@ -1337,7 +1344,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
       // half-tile is younger than the stores and the plain count is the right one.
       if (STREAM && (P == 1 || P == 3) && after_epilogue) wait_vmcnt<kPerHalf * (kAheadW4 - 4) + kStoresW4>();
       else wait_vmcnt<kPerHalf * (kAheadW4 - 4)>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      w4_wait_lds();
       if constexpr (!(ABL & 32)) GMD_PHASE_FENCE();
     } else {
       __builtin_amdgcn_sched_barrier(0);
