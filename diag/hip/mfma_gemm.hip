@@ -1073,7 +1073,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // One scalar 64-bit add per kind and PAIR instead of one per half-tile: with one wave per SIMD scalar instructions
   // between the MFMAs are not free either (seven add pairs fewer per pair of K-tiles were 3.8 k cycles per tile).
   auto dma = [my_pieces, o0 = off_imm[0], o1 = off_imm[1], o2 = off_imm[2], o3 = off_imm[3], b0 = off_imm_b[0], b1 = off_imm_b[1],
-              b2 = off_imm_b[2], b3 = off_imm_b[3], off_zero](const char* base, int slot, auto I, auto PAR, bool is_b, bool zero) {
+              b2 = off_imm_b[2], b3 = off_imm_b[3], off_zero](const char* base, int slot, auto I, auto PAR, bool is_b, bool zero,
+                                               auto EARLY_M0) {
     constexpr int i = decltype(I)::value;
     constexpr int kOdd = decltype(PAR)::value * BKB;
     const uint32_t lds = (uint32_t)(uintptr_t)(my_pieces + slot * kHalfBytes) - kOdd;
@@ -1086,7 +1087,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     // the clobber makes the hazard recognizer put a wait state between two pieces that are only two MFMAs apart (24 s_nop
     // per pair of K-tiles), and nothing the compiler generates in this loop writes M0 (scripts/check_gemm_codegen.py counts
     // the M0 writes between the first and the last MFMA of every instantiation).
-    if constexpr (i == 0 && !(ABL & 8))
+    if constexpr (i == 0 && !(ABL & 8) && !decltype(EARLY_M0)::value)
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(o), "s"(base), "n"(kOdd), "s"(lds)
                    : "memory", "m0");
     else
@@ -1162,6 +1163,12 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     stamp_pa = __builtin_amdgcn_s_memtime();
   }
 #endif
+  // In the K loop M0 is written three MFMAs ahead of piece 0 (EARLY_M0): the write needs a wait state before the load that
+  // uses it, and three MFMAs are one, where an s_nop of its own between two MFMAs is an issue slot.
+  auto set_m0 = [my_pieces](int slot, auto PAR) {
+    const uint32_t lds = (uint32_t)(uintptr_t)(my_pieces + slot * kHalfBytes) - decltype(PAR)::value * BKB;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(lds) : "memory", "m0");
+  };
   // What the DMA of one pair of K-tiles needs, worked out once per pair (fetch_pair): the four bases at the pair's even
   // K-tile, whether its odd K-tile is the zero one (GEN, odd count), and the MX scale tensors and K-tile index.
   const int last_kt = (int)(row_bytes / BKB) - 1;
@@ -1194,10 +1201,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     const bool zero = GEN && Par::value == 1 && pair_zero_odd;
     const char* base = pair_base[kind];
     if constexpr (GEN) base = zero ? zero_base : base;
-    dma(base, j, std::integral_constant<int, 0>{}, Par{}, kind == 1 || kind == 2, zero);
-    dma(base, j, std::integral_constant<int, 1>{}, Par{}, kind == 1 || kind == 2, zero);
-    dma(base, j, std::integral_constant<int, 2>{}, Par{}, kind == 1 || kind == 2, zero);
-    dma(base, j, std::integral_constant<int, 3>{}, Par{}, kind == 1 || kind == 2, zero);
+    dma(base, j, std::integral_constant<int, 0>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
+    dma(base, j, std::integral_constant<int, 1>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
+    dma(base, j, std::integral_constant<int, 2>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
+    dma(base, j, std::integral_constant<int, 3>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
     if constexpr (kMx) dma_scale(kind, min(pair_kt + Par::value, last_kt), j, pair_sa, pair_sb);
     if constexpr (kMx) {
 #pragma unroll
@@ -1295,10 +1302,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
           if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i);
         } else if (i < 12) {
           if constexpr (!(ABL & 2)) {
-            if (i == 8) dma(base, P, std::integral_constant<int, 0>{}, Par{}, is_b, zero);
-            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero);
-            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero);
-            else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero);
+            if (i == 8) dma(base, P, std::integral_constant<int, 0>{}, Par{}, is_b, zero, std::false_type{});
+            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero, std::false_type{});
+            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero, std::false_type{});
+            else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero, std::false_type{});
           }
         } else if (i == 12) {
           if constexpr (!(ABL & 2)) dma_scale(p, ikt, P, psa, psb);
@@ -1318,13 +1325,17 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
         if (i % kReadStep == 0 && i / kReadStep < 8) {
           if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i / kReadStep);
         }
+        static_assert(kDma0 >= 3, "M0 is written three MFMAs ahead of the first piece");
+        if (i == kDma0 - 3) {
+          if constexpr (!(ABL & 2) && !(ABL & 8)) set_m0(P, Par{});
+        }
         if (i >= kDma0 && (i - kDma0) % kDmaStep == 0 && (i - kDma0) / kDmaStep < 4) {
           if constexpr (!(ABL & 2)) {
             const int q = (i - kDma0) / kDmaStep;
-            if (q == 0) dma(base, P, std::integral_constant<int, 0>{}, Par{}, is_b, zero);
-            else if (q == 1) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero);
-            else if (q == 2) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero);
-            else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero);
+            if (q == 0) dma(base, P, std::integral_constant<int, 0>{}, Par{}, is_b, zero, std::true_type{});
+            else if (q == 1) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero, std::true_type{});
+            else if (q == 2) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero, std::true_type{});
+            else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero, std::true_type{});
           }
         }
         if (i <= (kDma0 + 3 * kDmaStep > 7 * kReadStep ? kDma0 + 3 * kDmaStep : 7 * kReadStep)) __builtin_amdgcn_sched_barrier(0);
