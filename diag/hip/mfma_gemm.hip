@@ -1104,17 +1104,40 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   const uint32_t* nsc_b = kMx && has_next ? scale_base(SB, ntn, wc) : sc_b;
   uint32_t lane_x4 = (uint32_t)lane * 4;
   asm volatile("" : "+v"(lane_x4));
-  auto dma_scale = [&](int kind, int kt, int slot, const uint32_t* sa_base, const uint32_t* sb_base) {
-    const uint32_t* src = ((kind == 0 || kind == 3) ? sa_base : sb_base) + ((size_t)(kind >= 2 ? ktiles : 0) + kt) * kScaleUnitDwords;
-    const uint32_t lds = (uint32_t)(uintptr_t)(my_scales + slot * 256);
-    // Wave-uniform, and meant for SGPRs: the distance from the tensor's start goes through readfirstlane (a no-op where the
-    // compiler has followed the uniformity, one VALU instruction where it has not) and back onto the kernel argument.
+  // Source of one scale unit, worked out once per pair and kind (fetch_pair) and held in SGPRs: the distance from the
+  // tensor's start goes through readfirstlane (a no-op where the compiler has followed the uniformity, one VALU instruction
+  // where it has not) and back onto the kernel argument.
+  auto scale_src = [&](int kind, int kt, const uint32_t* sa_base, const uint32_t* sb_base) {
     const bool is_a = kind == 0 || kind == 3;
+    const uint32_t* src = (is_a ? sa_base : sb_base) + ((size_t)(kind >= 2 ? ktiles : 0) + kt) * kScaleUnitDwords;
     const uint32_t dist = __builtin_amdgcn_readfirstlane((uint32_t)((const char*)src - (const char*)(is_a ? SA : SB)));
     src = (const uint32_t*)((const char*)(is_a ? SA : SB) + dist);
     asm volatile("" : "+s"(src));
-    // SGPR base + one VGPR offset (4 * lane) that never changes: a per-lane 64-bit address would be a VALU add per unit.
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_x4), "s"(src), "s"(lds) : "memory", "m0");
+    return src;
+  };
+  // One unit: SGPR base + one VGPR offset (4 * lane) that never changes (a per-lane 64-bit address would be a VALU add per
+  // unit).  PAR: as for the operands, the odd K-tile's unit is the even one's base read 256 bytes further on, through the
+  // immediate, with 256 taken off M0.  GEN with an odd count: the zero K-tile takes the last K-tile's scales (`same`).
+  auto dma_scale = [my_scales, lane_x4](const uint32_t* src, int slot, auto PAR, bool same) {
+    constexpr int kOdd = decltype(PAR)::value * 256;
+    uint32_t lds = (uint32_t)(uintptr_t)(my_scales + slot * 256) - kOdd;
+    if constexpr (GEN && kOdd != 0) {
+      if (same) {  // never taken outside the general instantiation's last real pair
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_x4), "s"(src), "s"(lds + kOdd) : "memory", "m0");
+        return;
+      }
+    }
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:%3" ::"v"(lane_x4), "s"(src), "s"(lds), "n"(kOdd)
+                 : "memory", "m0");
+  };
+  // The same in two statements for the K loop, M0 three MFMAs ahead of the load (see set_m0); not for GEN, whose zero
+  // K-tile changes the unit's place.
+  auto set_scale_m0 = [my_scales](int slot, auto PAR) {
+    const uint32_t lds = (uint32_t)(uintptr_t)(my_scales + slot * 256) - decltype(PAR)::value * 256;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(lds) : "memory", "m0");
+  };
+  auto scale_load = [lane_x4](const uint32_t* src, auto PAR) {
+    asm volatile("global_load_lds_dword %0, %1 offset:%2" ::"v"(lane_x4), "s"(src), "n"(decltype(PAR)::value * 256) : "memory");
   };
   auto read_scale = [&](int slot) { return *(const int*)(my_scales + slot * 256 + lane * 4); };
 
@@ -1174,9 +1197,9 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   const int last_kt = (int)(row_bytes / BKB) - 1;
   const char* pair_base[4];
   bool pair_zero_odd = false;
-  int pair_kt = 0;
   const uint32_t* pair_sa = sc_a;
   const uint32_t* pair_sb = sc_b;
+  const uint32_t* pair_scale[4] = {nullptr, nullptr, nullptr, nullptr};  // MX: the scale unit of each kind at the pair's even K-tile
   auto fetch_pair = [&](int bk) {  // bk: the pair's even K-tile
     const char* pa = gA;
     const char* pb = gB;
@@ -1190,9 +1213,11 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
       }
     }
     pair_zero_odd = GEN && bk + 1 > last_kt;
-    pair_kt = bk;
 #pragma unroll
-    for (int kind = 0; kind < 4; kind++) pair_base[kind] = piece_base(kind, bk, pa, pb);
+    for (int kind = 0; kind < 4; kind++) {
+      pair_base[kind] = piece_base(kind, bk, pa, pb);
+      if constexpr (kMx) pair_scale[kind] = scale_src(kind, bk, pair_sa, pair_sb);
+    }
   };
   // One half-tile's DMA outside the K loop's interleaving (the prologue).
   auto issue_half = [&](auto J) {
@@ -1205,7 +1230,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     dma(base, j, std::integral_constant<int, 1>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
     dma(base, j, std::integral_constant<int, 2>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
     dma(base, j, std::integral_constant<int, 3>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
-    if constexpr (kMx) dma_scale(kind, min(pair_kt + Par::value, last_kt), j, pair_sa, pair_sb);
+    if constexpr (kMx) dma_scale(pair_scale[kind], j, Par{}, zero);
     if constexpr (kMx) {
 #pragma unroll
       for (int t = 0; t < 8; t++) {
@@ -1277,9 +1302,6 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     if constexpr (GEN) base = zero ? zero_base : base;
     constexpr bool is_b = p == 1 || p == 2;
     using Par = std::integral_constant<int, par>;
-    const uint32_t* psa = pair_sa;
-    const uint32_t* psb = pair_sb;
-    const int ikt = min(pair_kt + par, last_kt);  // MX: the scale unit's K-tile
     int& sAf = (p < 2) ? sAL : sAH;
     int& sBf = (p == 0 || p == 3) ? (par ? sBY : sBX) : (par ? sBX : sBY);
     int& sRf = rk == 0 ? sAL : rk == 3 ? sAH : (rk == 1) == (rpar == 0) ? sBX : sBY;
@@ -1298,21 +1320,31 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
       }
       if constexpr (kMx) {
         // sixteen MFMAs per phase: reads behind the first eight, then the four pieces, the scale unit, the scale read
+        // M0 for the pieces goes out behind MFMA 5, M0 for the scale unit behind piece 3, each three MFMAs ahead of its load.
         if (i < 8) {
           if constexpr (!(ABL & 1)) read_one(Rf, rslot, rk == 0 || rk == 3, i);
+          if constexpr (!(ABL & 2)) {
+            if (i == 5) set_m0(P, Par{});
+          }
         } else if (i < 12) {
           if constexpr (!(ABL & 2)) {
-            if (i == 8) dma(base, P, std::integral_constant<int, 0>{}, Par{}, is_b, zero, std::false_type{});
-            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero, std::false_type{});
-            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero, std::false_type{});
-            else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero, std::false_type{});
+            if (i == 8) dma(base, P, std::integral_constant<int, 0>{}, Par{}, is_b, zero, std::true_type{});
+            else if (i == 9) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero, std::true_type{});
+            else if (i == 10) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero, std::true_type{});
+            else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero, std::true_type{});
+            if constexpr (!GEN) {
+              if (i == 11) set_scale_m0(P, Par{});
+            }
           }
-        } else if (i == 12) {
-          if constexpr (!(ABL & 2)) dma_scale(p, ikt, P, psa, psb);
         } else if (i == 13) {
           if constexpr (!(ABL & 1)) sRf = read_scale(rslot);
+        } else if (i == 14) {
+          if constexpr (!(ABL & 2)) {
+            if constexpr (GEN) dma_scale(pair_scale[p], P, Par{}, zero);
+            else scale_load(pair_scale[p], Par{});
+          }
         }
-        if (i < 14) __builtin_amdgcn_sched_barrier(0);
+        if (i < 15) __builtin_amdgcn_sched_barrier(0);
       } else {
         // 32 (bf16) or 64 (fp8) MFMAs per phase: fragment read j behind MFMA j*kReadStep, DMA piece q behind MFMA
         // kDma0 + q*kDmaStep.  With one wave per SIMD a memory instruction right behind another one costs MFMA issue
