@@ -899,9 +899,19 @@ __global__ __launch_bounds__(kThreads) void gemm_ps_kernel(const char* __restric
 //   vmcnt(16) (half-tiles up to g+4 landed, four still in flight), lgkmcnt(0) and
 //   a barrier; the phases in between end with nothing.
 // * Slot (g+8) % 8 was last read in phase g-2, at least one barrier earlier.
-// * Measured (8192^3, one device, interleaved): fewer LDS bytes buy +2-5 % clock at
-//   +4-6 % cycles (exposed barriers and issue gaps).  Net: 2 % behind the eight-wave
-//   kernel on bf16, 1.5-2.5 % ahead on MX-fp8.
+// * With one wave per SIMD there is nothing to issue from while this wave issues an
+//   instruction that is not an MFMA: every scalar or vector ALU instruction, s_nop and
+//   avoidable s_waitcnt between two MFMAs is matrix-pipe time (3 to 6 cycles each,
+//   512 phases per 8192-deep tile).  The K loop therefore holds MFMAs, fragment reads,
+//   DMA pieces, one M0 write per half-tile and one wait per phase, and nothing else:
+//   LDS read bases for the far half of the ring in registers of their own, half-tile
+//   bases computed once per pair of K-tiles (the odd K-tile goes through the
+//   instruction's immediate), M0 written three MFMAs ahead of the piece that needs
+//   it, the LDS wait stated once per phase in a form the compiler can see.
+//   284 k -> 272 k cycles per tile on bf16 (262 k of MFMA issue).
+// * Measured (8192^3 bf16, one rocprofv3 pass): 701.0 us and 1,219,217 cycles
+//   against hipBLASLt's 704.6 us and 1,221,069; 1-2 % ahead of the eight-wave
+//   kernels on every data type.
 constexpr int kThreadsW4 = 256;
 constexpr int kAheadW4 = 8;
 
