@@ -385,7 +385,10 @@ constexpr int kAheadDefault = 7;       // issue distance in half-tiles (5..7 wit
 // four tile rows, so the ~32 tiles an XCD has in flight form a 4 x 8 block that
 // shares 4 A panels and 8 B panels in its L2 instead of 1 and 32.
 __device__ __forceinline__ void tile_of(int wgid, int tiles_m, int tiles_n, int* tm, int* tn) {
-  constexpr int G = 4;
+#ifndef GMD_TILE_G
+#define GMD_TILE_G 4  // tile rows per column-major group; other values are an experiment's business (-DGMD_TILE_G=)
+#endif
+  constexpr int G = GMD_TILE_G;
   const int per_group = G * tiles_n;
   const int group = wgid / per_group;
   const int first = group * G;

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from k8s_gpu_monitor_amd import _lib  # noqa: E402
 
 _orig_find = _lib._find
-_lib._find = lambda name: _orig_find("libgpumon_diag_ablate.so" if name == "libgpumon_diag.so" else name)
+_lib._find = lambda name: _orig_find(os.environ.get("GEMM_TL_LIB", "libgpumon_diag_ablate.so") if name == "libgpumon_diag.so" else name)
 from k8s_gpu_monitor_amd.ops import diag  # noqa: E402
 
 lib = diag._lib()
