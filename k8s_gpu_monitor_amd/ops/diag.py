@@ -326,7 +326,8 @@ def link_grade(gbps, bad=None, floor_gbps=0.0, warn_ratio=0.0, fail_ratio=0.0):
 
 def gemm_launch(dtype, a_ptr, b_ptr, c_ptr, m, n, k, stream=None, scale_a=None, scale_b=None):
     """C[M,N] (bf16) = A[M,K] @ B[N,K]^T on caller memory.  dtype "mxfp8" takes the two packed E8M0 scale tensors
-    (mx_pack_scales) as scale_a / scale_b device pointers; "fp8" is unscaled e4m3."""
+    (mx_pack_scales) as scale_a / scale_b device pointers; "fp8" is unscaled e4m3.  M and N in multiples of 8 (256
+    for "mxfp8"), K in multiples of 64 ("bf16") or 128; operands 16-byte aligned."""
     if dtype == "mxfp8":
         if scale_a is None or scale_b is None:
             raise DiagError(-1, "gmd_gemm_launch_mx: mxfp8 needs scale_a and scale_b (packed E8M0 scales)")
@@ -339,7 +340,8 @@ def gemm_launch(dtype, a_ptr, b_ptr, c_ptr, m, n, k, stream=None, scale_a=None, 
 
 
 def mx_pack_scales(src_ptr, dst_ptr, rows, k, stream=None):
-    """Row-major uint8 E8M0 scales [rows][k/32] -> the packed layout the MX-fp8 GEMM reads (same byte count)."""
+    """Row-major uint8 E8M0 scales [rows][k/32] -> the packed layout the MX-fp8 GEMM reads (same byte count);
+    rows in multiples of 128, k of 128."""
     rc = _lib().gmd_mx_pack_scales(C.c_void_p(src_ptr), C.c_void_p(dst_ptr), rows, k, C.c_void_p(stream))
     if rc:
         raise DiagError(rc, "gmd_mx_pack_scales")
