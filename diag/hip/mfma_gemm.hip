@@ -1666,9 +1666,9 @@ __global__ __launch_bounds__(256) void peak_kernel(float* __restrict__ out, int 
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = f32x4{(float)i, (float)lane, 0.5f * i, 1.f};  // distinct chains: nothing to merge
-    for (int it = 0; it < iters; it++)
+    for (int it = 0; it < iters / 8; it++)  // 64 MFMAs per branch: a taken branch is ~13 cycles in which the wave issues nothing
 #pragma unroll
-      for (int i = 0; i < 8; i++) PEAK_MFMA("v_mfma_f32_16x16x32_bf16", acc[i], a, b);
+      for (int i8 = 0, i = 0; i8 < 64; i8++, i = i8 & 7) PEAK_MFMA("v_mfma_f32_16x16x32_bf16", acc[i], a, b);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       PEAK_DRAIN(acc[i]);
@@ -1680,9 +1680,9 @@ __global__ __launch_bounds__(256) void peak_kernel(float* __restrict__ out, int 
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = f32x4{(float)i, (float)lane, 0.5f * i, 1.f};  // distinct chains: nothing to merge
-    for (int it = 0; it < iters; it++)
+    for (int it = 0; it < iters / 8; it++)  // 64 MFMAs per branch: a taken branch is ~13 cycles in which the wave issues nothing
 #pragma unroll
-      for (int i = 0; i < 8; i++) PEAK_MFMA("v_mfma_f32_16x16x32_fp8_fp8", acc[i], a, b);
+      for (int i8 = 0, i = 0; i8 < 64; i8++, i = i8 & 7) PEAK_MFMA("v_mfma_f32_16x16x32_fp8_fp8", acc[i], a, b);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       PEAK_DRAIN(acc[i]);
@@ -1698,9 +1698,9 @@ __global__ __launch_bounds__(256) void peak_kernel(float* __restrict__ out, int 
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = f32x4{(float)i, (float)lane, 0.5f * i, 1.f};  // distinct chains: nothing to merge
-    for (int it = 0; it < iters; it++)
+    for (int it = 0; it < iters / 8; it++)  // 64 MFMAs per branch: a taken branch is ~13 cycles in which the wave issues nothing
 #pragma unroll
-      for (int i = 0; i < 8; i++)
+      for (int i8 = 0, i = 0; i8 < 64; i8++, i = i8 & 7)
         acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -1712,9 +1712,9 @@ __global__ __launch_bounds__(256) void peak_kernel(float* __restrict__ out, int 
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = f32x4{(float)i, (float)lane, 0.5f * i, 1.f};  // distinct chains: nothing to merge
-    for (int it = 0; it < iters; it++)
+    for (int it = 0; it < iters / 8; it++)  // 64 MFMAs per branch: a taken branch is ~13 cycles in which the wave issues nothing
 #pragma unroll
-      for (int i = 0; i < 8; i++) PEAK_MFMA("v_mfma_f32_16x16x4_f32", acc[i], a, b);
+      for (int i8 = 0, i = 0; i8 < 64; i8++, i = i8 & 7) PEAK_MFMA("v_mfma_f32_16x16x4_f32", acc[i], a, b);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       PEAK_DRAIN(acc[i]);
