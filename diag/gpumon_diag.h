@@ -154,7 +154,8 @@ GMD_API int gmd_mfma_peak(int device, int dtype, double seconds, gmd_mfma_result
 GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, int verify,
                             gmd_mfma_result_t* out);
 /* One GEMM on caller memory.  A: [M,K] row-major, B: [N,K] row-major (i.e. B^T), C: [M,N] row-major bf16.
- * GMD_DT_BF16: A, B bf16.  GMD_DT_FP8: A, B OCP e4m3, unscaled (mfma_f32_16x16x32_fp8_fp8).
+ * GMD_DT_BF16: A, B bf16.  GMD_DT_FP8: A, B OCP e4m3, unscaled (mfma_f32_16x16x128_f8f6f4, twice the rate of
+ * mfma_f32_16x16x32_fp8_fp8, which schedules 0, 1, 3, 4, 5 and 7 run).
  * M, N multiples of 8 (tiles that reach beyond the matrix and odd K-tile counts run a general instantiation of the
  * four-wave kernel); K a multiple of 64 (bf16) / 128 (fp8), i.e. whole 128-byte K-tiles.  GMD_DT_MXFP8 needs scales
  * and M, N in multiples of 256: gmd_gemm_launch_mx. */
@@ -172,8 +173,10 @@ GMD_API int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int r
  * 3 = eight waves x 128x64 as one stream per CU over its tiles (needs more tiles than CUs and >= 4 K-tiles);
  * 4 / 5 = schedule 1 with the narrow / the cached epilogue (A/B references); 6 = schedule 2 as one stream per
  * CU (A/B reference, same conditions as 3, otherwise 2 runs).  Partial tiles run the general four-wave kernel
- * whatever the schedule, an odd number of K-tiles does unless the schedule is 0.  MX-fp8 runs 2, 6 or 0.  All schedules give
- * bit-identical results.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
+ * whatever the schedule, an odd number of K-tiles does unless the schedule is 0.  MX-fp8 runs 2, 6 or 0.
+ * 7 = schedule 2 on the K=32 instruction for unscaled fp8 (2 for the other data types).  All schedules give
+ * bit-identical results, except that unscaled fp8 has two groups of them, one per MFMA instruction (K=128: -1, 2, 6;
+ * K=32: the others), whose sums differ in the order of their additions.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
 
 /* Timing-only ablation builds (make diag-ablate): per-workgroup pairs (shader-clock ticks,

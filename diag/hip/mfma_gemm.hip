@@ -925,7 +925,8 @@ constexpr int kAheadW4 = 8;
 // states; the epilogue's reads come after W4_DRAIN.
 // `sub`: bf16 k-substep (0 / 1); fp8 k-substep * 2 + half (0..3); unused for MX-fp8, whose scale dwords
 // sa / sb hold four E8M0 bytes each and whose op_sel fields pick byte MBQ (A, second operand) and NBQ (B, first).
-template <int DT, int MBQ, int NBQ>
+// UNIT (with DT MX-fp8): no scales; the same K=128 instruction in its unscaled form.
+template <int DT, int MBQ, int NBQ, bool UNIT = false>
 __device__ __forceinline__ void mfma_step_t(f32x4& acc, const i32x8& a, const i32x8& b, int sub, int sa, int sb) {
   if constexpr (DT == GMD_DT_BF16) {
     const i32x4 bh = sub ? __builtin_shufflevector(b, b, 4, 5, 6, 7) : __builtin_shufflevector(b, b, 0, 1, 2, 3);
@@ -938,16 +939,18 @@ __device__ __forceinline__ void mfma_step_t(f32x4& acc, const i32x8& a, const i3
     const i32x2 ah = sub == 0 ? __builtin_shufflevector(a, a, 0, 1) : sub == 1 ? __builtin_shufflevector(a, a, 2, 3)
                      : sub == 2 ? __builtin_shufflevector(a, a, 4, 5) : __builtin_shufflevector(a, a, 6, 7);
     asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+a"(acc) : "v"(bh), "v"(ah));
+  } else if constexpr (UNIT) {
+    asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
   } else {
     asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[%5,%6,0] op_sel_hi:[%7,%8,0]"
                  : "+a"(acc)
                  : "v"(b), "v"(a), "v"(sb), "v"(sa), "n"(NBQ & 1), "n"(MBQ & 1), "n"(NBQ >> 1), "n"(MBQ >> 1));
   }
 }
-template <int DT>
+template <int DT, bool UNIT = false>
 __device__ __forceinline__ void mfma_step(f32x4& acc, const i32x8& a, const i32x8& b, int sub, int mbq, int nbq, int sa, int sb) {
-  if constexpr (DT != GMD_DT_MXFP8) {
-    mfma_step_t<DT, 0, 0>(acc, a, b, sub, 0, 0);
+  if constexpr (DT != GMD_DT_MXFP8 || UNIT) {
+    mfma_step_t<DT, 0, 0, UNIT>(acc, a, b, sub, 0, 0);
   } else {
     switch (mbq * 4 + nbq) {  // constant once the caller's loop is unrolled
 #define GMD_W4_CASE(MBQ, NBQ) \
@@ -977,12 +980,17 @@ __device__ __forceinline__ void w4_wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07
 // GEN: any M, any N that is a multiple of 8 (bf16, fp8), any number of K-tiles.  Rows beyond the matrix are fetched
 // from its last row (their products land in accumulators that are never stored), stores are bounds-tested, and an odd
 // K-tile count is completed by a K-tile of zeros.  The full-tile, even-count instantiation pays for none of it.
-template <int DT, int ABL = 0, int EPI = 1, bool STREAM = false, bool GEN = false>
+// UNIT (DT MX-fp8 only): unscaled fp8 on the K=128 instruction.  The LDS image, the fragment layout and the interleaving
+// are MX-fp8's; there are no scale tensors, no scale ring and no fifth memory instruction per half-tile.  This is how
+// GMD_DT_FP8 runs: the K=128 instruction does in 32 cycles what four of the K=32 fp8 instruction do in 64.
+template <int DT, int ABL = 0, int EPI = 1, bool STREAM = false, bool GEN = false, bool UNIT = false>
 __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                              __bf16* __restrict__ C, int M, int N, size_t row_bytes,
                                                              const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB) {
-  constexpr bool kMx = DT == GMD_DT_MXFP8;
-  constexpr int kPerHalf = kMx ? 5 : 4;  // vector-memory instructions a wave issues per half-tile (MX: + its scale unit)
+  constexpr bool kMx = DT == GMD_DT_MXFP8;    // the K=128 instruction and its layouts
+  constexpr bool kScaled = kMx && !UNIT;      // ... with scale tensors
+  static_assert(!UNIT || kMx, "UNIT is a form of the MX-fp8 kernel");
+  constexpr int kPerHalf = kScaled ? 5 : 4;  // vector-memory instructions a wave issues per half-tile (MX: + its scale unit)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1111,10 +1119,10 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   const int ktiles = (int)(row_bytes / BKB);
   char* const my_scales = smem + kLdsBytes + wave * 8 * 256;
   auto scale_base = [&](const uint32_t* S, int t, int w) { return S + (size_t)(4 * t + 2 * w) * ktiles * kScaleUnitDwords; };
-  const uint32_t* sc_a = kMx ? scale_base(SA, tm, wr) : nullptr;  // wave-uniform
-  const uint32_t* sc_b = kMx ? scale_base(SB, tn, wc) : nullptr;
-  const uint32_t* nsc_a = kMx && has_next ? scale_base(SA, ntm, wr) : sc_a;
-  const uint32_t* nsc_b = kMx && has_next ? scale_base(SB, ntn, wc) : sc_b;
+  const uint32_t* sc_a = kScaled ? scale_base(SA, tm, wr) : nullptr;  // wave-uniform
+  const uint32_t* sc_b = kScaled ? scale_base(SB, tn, wc) : nullptr;
+  const uint32_t* nsc_a = kScaled && has_next ? scale_base(SA, ntm, wr) : sc_a;
+  const uint32_t* nsc_b = kScaled && has_next ? scale_base(SB, ntn, wc) : sc_b;
   uint32_t lane_x4 = (uint32_t)lane * 4;
   asm volatile("" : "+v"(lane_x4));
   // Source of one scale unit, worked out once per pair and kind (fetch_pair) and held in SGPRs: the distance from the
@@ -1229,7 +1237,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
 #pragma unroll
     for (int kind = 0; kind < 4; kind++) {
       pair_base[kind] = piece_base(kind, bk, pa, pb);
-      if constexpr (kMx) pair_scale[kind] = scale_src(kind, bk, pair_sa, pair_sb);
+      if constexpr (kScaled) pair_scale[kind] = scale_src(kind, bk, pair_sa, pair_sb);
     }
   };
   // One half-tile's DMA outside the K loop's interleaving (the prologue).
@@ -1243,7 +1251,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     dma(base, j, std::integral_constant<int, 1>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
     dma(base, j, std::integral_constant<int, 2>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
     dma(base, j, std::integral_constant<int, 3>{}, Par{}, kind == 1 || kind == 2, zero, std::false_type{});
-    if constexpr (kMx) dma_scale(pair_scale[kind], j, Par{}, zero);
+    if constexpr (kScaled) dma_scale(pair_scale[kind], j, Par{}, zero);
     if constexpr (kMx) {
 #pragma unroll
       for (int t = 0; t < 8; t++) {
@@ -1273,7 +1281,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   for (int j = 0; j < 8; j++) read_one(aL, 0, true, j);
 #pragma unroll
   for (int j = 0; j < 8; j++) read_one(bX, 1, false, j);
-  if constexpr (kMx) {
+  if constexpr (kScaled) {
     sAL = read_scale(0);
     sBX = read_scale(1);
   }
@@ -1328,8 +1336,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
       const int sub = i >> 4, mb = (i >> 2) & 3, nb = i & 3;
       if constexpr (!(ABL & 4)) {
         // mfma_step's first matrix operand is its `b`: rows dealt -> A goes first (result lanes run along N)
-        if constexpr (kRowsDealt) mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Bf[nb], Af[mb], sub, nb, mb, sBf, sAf);
-        else mfma_step<DT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], sub, mb, nb, sAf, sBf);
+        if constexpr (kRowsDealt) mfma_step<DT, UNIT>(acc[MB0 + mb][NB0 + nb], Bf[nb], Af[mb], sub, nb, mb, sBf, sAf);
+        else mfma_step<DT, UNIT>(acc[MB0 + mb][NB0 + nb], Af[mb], Bf[nb], sub, mb, nb, sAf, sBf);
       }
       if constexpr (kMx) {
         // sixteen MFMAs per phase: reads behind the first eight, then the four pieces, the scale unit, the scale read
@@ -1345,19 +1353,19 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
             else if (i == 9) dma(base, P, std::integral_constant<int, 1>{}, Par{}, is_b, zero, std::true_type{});
             else if (i == 10) dma(base, P, std::integral_constant<int, 2>{}, Par{}, is_b, zero, std::true_type{});
             else dma(base, P, std::integral_constant<int, 3>{}, Par{}, is_b, zero, std::true_type{});
-            if constexpr (!GEN) {
+            if constexpr (kScaled && !GEN) {
               if (i == 11) set_scale_m0(P, Par{});
             }
           }
         } else if (i == 13) {
-          if constexpr (!(ABL & 1)) sRf = read_scale(rslot);
+          if constexpr (kScaled && !(ABL & 1)) sRf = read_scale(rslot);
         } else if (i == 14) {
-          if constexpr (!(ABL & 2)) {
+          if constexpr (kScaled && !(ABL & 2)) {
             if constexpr (GEN) dma_scale(pair_scale[p], P, Par{}, zero);
             else scale_load(pair_scale[p], Par{});
           }
         }
-        if (i < 15) __builtin_amdgcn_sched_barrier(0);
+        if (i < (kScaled ? 15 : 12)) __builtin_amdgcn_sched_barrier(0);
       } else {
         // 32 (bf16) or 64 (fp8) MFMAs per phase: fragment read j behind MFMA j*kReadStep, DMA piece q behind MFMA
         // kDma0 + q*kDmaStep.  With one wave per SIMD a memory instruction right behind another one costs MFMA issue
@@ -1386,7 +1394,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
         if (i <= (kDma0 + 3 * kDmaStep > 7 * kReadStep ? kDma0 + 3 * kDmaStep : 7 * kReadStep)) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if constexpr (kMx) asm volatile("" ::"v"(sAf), "v"(sBf));
+    if constexpr (kScaled) asm volatile("" ::"v"(sAf), "v"(sBf));
     // Keep both operand sets whole until the phase's last MFMA, so that no half of them is handed to one of
     // this phase's ds_reads or address computations while MFMAs that read it are still to issue.
 #pragma unroll
@@ -1453,9 +1461,9 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     __builtin_amdgcn_sched_barrier(0);
     wgid += tile_step;
     tm = ntm, tn = ntn, gA = nA, gB = nB;
-    if constexpr (kMx) sc_a = nsc_a, sc_b = nsc_b;
+    if constexpr (kScaled) sc_a = nsc_a, sc_b = nsc_b;
     look_ahead();
-    if constexpr (kMx) {
+    if constexpr (kScaled) {
       nsc_a = has_next ? scale_base(SA, ntm, wr) : sc_a;
       nsc_b = has_next ? scale_base(SB, ntn, wc) : sc_b;
     }
@@ -1747,9 +1755,11 @@ double peak_flops_per_mfma(int dt) {
 // loop (A/B baseline; also what odd K-tile counts run); 1 = eight waves of 128 x 64, one workgroup per tile;
 // 2 = four waves of 128 x 128; 3 = eight waves of 128 x 64 as one stream per CU over its tiles (gemm_ps_kernel);
 // 4 / 5 = schedule 1 with the narrow / the wide but cached epilogue (A/B references for store_acc);
-// 6 = four waves of 128 x 128 as one stream per CU over its tiles (gemm_w4_kernel<.., STREAM>).
+// 6 = four waves of 128 x 128 as one stream per CU over its tiles (gemm_w4_kernel<.., STREAM>);
+// 7 = schedule 2 on the K=32 fp8 instruction (unscaled fp8 only, where 2 and 6 run the K=32 sums' products on the K=128
+// instruction, which adds them up in another order: an A/B reference; schedule 2 for the other data types).
 constexpr int kVariantUnset = -2;
-constexpr int kVariantMax = 6;
+constexpr int kVariantMax = 7;
 int g_gemm_variant = kVariantUnset;
 
 int gemm_variant() {
@@ -1813,8 +1823,18 @@ int launch_gemm_t(const GemmArgs& g) {
   const bool stream_ok = full_tiles && pairs && ktiles >= 4 && grid > persistent_grid();  // more tiles than CUs, two pairs per tile
   // Partial tiles or an odd number of K-tiles: the general instantiation of the four-wave kernel, whatever was asked for
   // (schedule 0 takes any K-tile count as well, but full tiles only).
-  if (!full_tiles || (!pairs && gemm_variant() != 0))
+  // Unscaled fp8 runs on the K=128 instruction (the MX-fp8 kernel without scales, UNIT); schedule 7 asks for the four-wave
+  // kernel on the K=32 instruction instead, the form whose sums agree bit for bit with the eight-wave schedules.
+  // The K=128 instruction adds the products up in another order, so the schedules that are A/B references for one another
+  // (0, 1, 3, 4, 5 and 7) all stay on the K=32 one, for every shape.
+  constexpr bool kFp8 = DT == GMD_DT_FP8;
+  const int asked = gemm_variant();
+  const bool fp8_wide = kFp8 && (asked < 0 || asked > kVariantMax || asked == 2 || asked == 6);
+  if (!full_tiles || (!pairs && gemm_variant() != 0)) {
+    if (fp8_wide)
+      return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 1, false, true, true>, grid, kThreadsW4, kLdsBytes, g);
     return launch_lds(gemm_w4_kernel<DT, 0, 1, false, true>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
+  }
 #define GMD_LAUNCH(KFN, GRID, THREADS) return launch_lds(KFN, GRID, THREADS, kLdsBytes, g)
 #ifdef GMD_GEMM_ABLATE
   // Timing-only builds of the per-tile pipeline with parts removed (10 + mask), other issue distances (20 + d),
@@ -1881,7 +1901,11 @@ int launch_gemm_t(const GemmArgs& g) {
   if (!pairs) variant = 0;
   if (variant == 3 && !stream_ok) variant = 1;
   if (variant == 6 && !stream_ok) variant = 2;
-  if (variant == 2) return launch_lds(gemm_w4_kernel<DT>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
+  if (variant == 7 && !kFp8) variant = 2;
+  if (fp8_wide && variant == 2) return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 1, false, false, true>, grid, kThreadsW4, kLdsBytes, g);
+  if (fp8_wide && variant == 6)
+    return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 1, true, false, true>, persistent_grid(), kThreadsW4, kLdsBytes, g);
+  if (variant == 2 || variant == 7) return launch_lds(gemm_w4_kernel<DT>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
   if (variant == 6)
     return launch_lds(gemm_w4_kernel<DT, 0, 1, true>, persistent_grid(), kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
   if constexpr (!kMx) {

@@ -193,7 +193,8 @@ def gemm_set_variant(variant):
     """-1 = fastest schedule per dtype and shape (default), 0 = simple double-buffered loop (A/B baseline),
     1 = eight waves x 128x64 per tile, 2 = four waves x 128x128 (accumulators in AGPRs), 3 = eight waves x 128x64
     as one stream per CU over its tiles, 4 / 5 = schedule 1 with the narrow / cached epilogue, 6 = schedule 2 as one
-    stream per CU (A/B reference; slower than 2, see docs/diagnostics.md)."""
+    stream per CU (A/B reference; slower than 2, see docs/diagnostics.md), 7 = schedule 2 on the K=32 fp8 instruction
+    (unscaled fp8 runs -1, 2 and 6 on the K=128 instruction, at twice the rate, and the others on the K=32 one)."""
     rc = _lib().gmd_gemm_set_variant(int(variant))
     if rc:
         raise DiagError(rc, "gmd_gemm_set_variant")

@@ -1,6 +1,6 @@
 """What the general instantiation of the four-wave GEMM costs: shapes with partial tiles and odd K-tile counts next to
-the nearest full-tile, even-count shape, bf16 and fp8, with torch.matmul (hipBLASLt) for bf16.  Writes
-gpurun_out/gemm_shapes.json."""
+the nearest full-tile, even-count shape, bf16 and fp8, with the vendor's kernel on the same operands (hipBLASLt through
+torch.matmul for bf16, through torch._scaled_mm with unit scales for fp8).  Writes gpurun_out/gemm_shapes.json."""
 import json
 import os
 import sys
@@ -33,7 +33,7 @@ def timed(fn, n=30):
 
 for dtype in ("bf16", "fp8"):
     kt = 64 if dtype == "bf16" else 128
-    for (m, n, k) in [(8192, 8192, 8192), (8192, 8192, 8192 + kt), (8200, 8200, 8192), (8000, 8000, 8192), (4000, 4104, 4096 + kt),
+    for (m, n, k) in [(2048, 2048, 2048), (4096, 4096, 4096), (8192, 8192, 8192), (16384, 16384, 16384), (8192, 8192, 8192 + kt), (8200, 8200, 8192), (8000, 8000, 8192), (4000, 4104, 4096 + kt),
                       (1000, 520, 5 * kt)]:
         a = torch.randn(m, k, device=dev)
         b = torch.randn(n, k, device=dev)
@@ -45,6 +45,15 @@ for dtype in ("bf16", "fp8"):
             bt = b.t()
             tms = timed(lambda: torch.matmul(a, bt, out=c))
             row.update({"torch_ms": round(tms, 4), "torch_tflops": round(2.0 * m * n * k / tms / 1e9, 1)})
+        else:
+            one = torch.ones((), device=dev)
+            bt = b.t()
+            try:
+                tms = timed(lambda: torch._scaled_mm(a, bt, scale_a=one, scale_b=one, out_dtype=torch.bfloat16))
+                row.update({"torch_ms": round(tms, 4), "torch_tflops": round(2.0 * m * n * k / tms / 1e9, 1)})
+            except Exception as e:  # shapes the vendor's fp8 path does not take (it wants multiples of 16)
+                row["torch_error"] = str(e).splitlines()[0][:120]
+        del a, b, c
         print(row, flush=True)
         out.append(row)
 os.makedirs("gpurun_out", exist_ok=True)

@@ -21,7 +21,7 @@ def test_no_accumulator_is_read_before_the_matrix_pipe_is_drained():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert r.returncode == 0, r.stdout + r.stderr
     # three data types x (per tile, general, stream)
-    assert len(lines) == 9 and all(ln.endswith(": ok") for ln in lines), r.stdout
+    assert len(lines) == 12 and all(ln.endswith(": ok") for ln in lines), r.stdout
 
 
 def test_the_checker_sees_a_read_that_comes_too_early():

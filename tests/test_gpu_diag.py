@@ -269,20 +269,27 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
                           (4352, 4352, 4 * kt), (4352, 4608, 10 * kt)]:  # 289 / 306 tiles: more than CUs, variant 3 streams
             G = _Gemm(diag, dev, m, n, k, dtype, seed=k)
             outs = {}
-            for variant in (0, 1, 2, 3, 4, 5, 6, -1):
+            for variant in (0, 1, 2, 3, 4, 5, 6, 7, -1):
                 diag.gemm_set_variant(variant)
                 c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
                 G.launch(c)
                 torch.cuda.synchronize()
                 outs[variant] = c
-                if variant in (1, 2, 3, 6):  # 4 and 5 differ from 1 in the epilogue only
+                if variant in (1, 2, 3, 6, 7):  # 4 and 5 differ from 1 in the epilogue only
                     c2 = torch.empty_like(c)
                     for _ in range(20):
                         G.launch(c2)
                     torch.cuda.synchronize()
                     assert torch.equal(c2, c), (variant, m, n, k)
-            for variant in (1, 2, 3, 4, 5, 6, -1):
-                assert torch.equal(outs[0], outs[variant]), (variant, m, n, k)
+            # Unscaled fp8: the default, 2 and 6 run on the K=128 instruction, which adds the same products up in another
+            # order; 7 is schedule 2 on the K=32 instruction.  Each group is identical within itself.
+            wide = (2, 6, -1) if dtype == "fp8" else ()
+            for variant in (1, 2, 3, 4, 5, 6, 7, -1):
+                assert torch.equal(outs[2 if variant in wide else 0], outs[variant]), (variant, m, n, k)
+            if wide:
+                ref = G.ref()
+                for v in (0, 2):
+                    assert ((outs[v].float() - ref).abs().max() / ref.abs().max()).item() < 6e-3, (v, m, n, k)
         with pytest.raises(diag.DiagError):
             diag.gemm_set_variant(9)
     finally:
@@ -297,7 +304,7 @@ def test_gemm_takes_the_operators_shape(diag, dev, dtype, shape):
     bounds test), any number of K-tiles (an odd count is completed by a K-tile of zeros).  The output is compared with
     fp32 everywhere, a guard band behind C must stay untouched, and every schedule that can be asked for gives the
     same bits (they all route to the general instantiation of the four-wave kernel; with full tiles schedule 0 runs its
-    own loop)."""
+    own loop).  Unscaled fp8 has two such instantiations, one per MFMA instruction (K=128: default, 2, 6; K=32: the rest)."""
     m, n, kt = shape
     k = kt * (64 if dtype == "bf16" else 128)
     G = _Gemm(diag, dev, m, n, k, dtype, seed=m + n + k)
@@ -311,13 +318,20 @@ def test_gemm_takes_the_operators_shape(diag, dev, dtype, shape):
     err = (c.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
     assert err < 6e-3, err
     assert (buf[m * n:] == 7.0).all()
+    narrow = None
     try:
-        for variant in (0, 1, 2, 3, 6):
+        for variant in (0, 1, 2, 3, 6, 7):
             diag.gemm_set_variant(variant)
             c2 = torch.empty_like(c)
             G.launch(c2)
             torch.cuda.synchronize()
-            assert torch.equal(c2, c), variant
+            if dtype == "fp8" and variant not in (2, 6):  # on the K=32 instruction: another order of summation
+                err = (c2.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+                assert err < 6e-3, (variant, err)
+                assert narrow is None or torch.equal(c2, narrow), variant
+                narrow = c2
+            else:
+                assert torch.equal(c2, c), variant
     finally:
         diag.gemm_set_variant(-1)
 
@@ -358,12 +372,12 @@ def test_gemm_stress_and_pipe_peak(diag):
 
 def test_gemm_throughput_floors_at_the_headline_shape(diag, dev):
     """8192^3, the shape of the bench.  Back-to-back launches timed with device events: floors at 85 % of what the
-    kernels measure this way (bf16 1600-1635, unscaled fp8 2090, MX-fp8 with real scales 3090-3115 TFLOP/s:
-    profiles/gemm_ab.json; hipBLASLt's bf16 kernel holds 1650 on the same chip, profiles/gemm_vendor_clock.md).
+    kernels measure this way (bf16 1600-1635, unscaled fp8 3230-3320, MX-fp8 with real scales 3090-3115 TFLOP/s:
+    profiles/gemm_ab.json, profiles/gemm_shapes.json; hipBLASLt holds 1650 (bf16) and 3200-3240 (fp8) on the same chip).
     The stress driver adds a checksum pass over C after every launch and an fp32 reference check, so its own figure
-    is lower (bf16 1320, fp8 1760, MX-fp8 2420 in a 5 s run): 85 % of those as well."""
+    is lower (bf16 1320, fp8 2520, MX-fp8 2420 in a 5 s run): 85 % of those as well."""
     flop = 2.0 * 8192 ** 3
-    for dtype, launch_floor, stress_floor in (("bf16", 1360.0, 1120.0), ("fp8", 1775.0, 1495.0), ("mxfp8", 2630.0, 2060.0)):
+    for dtype, launch_floor, stress_floor in (("bf16", 1360.0, 1120.0), ("fp8", 2700.0, 2100.0), ("mxfp8", 2630.0, 2060.0)):
         G = _Gemm(diag, dev, 8192, 8192, 8192, dtype, seed=7)
         c = torch.empty(8192, 8192, dtype=torch.bfloat16, device=dev)
         for _ in range(30):
