@@ -60,13 +60,18 @@ for s in $STEPS; do
       # One counter pass per run (rocprofv3 does not multiplex): SQ pass, L2 read pass, L2 write/hit pass.
       export TMPDIR=/tmp
       D="$PWD/build/bin/gpumon-diag"
-      for target in "gemm_bf16:gemm --dtype bf16 --seconds 0.05 --no-telemetry" "gemm_mxfp8:gemm --dtype mxfp8 --seconds 0.05 --no-telemetry" \
+      for target in "gemm_bf16:gemm --dtype bf16 --seconds 0.05 --no-telemetry" "gemm_fp8:gemm --dtype fp8 --seconds 0.05 --no-telemetry" \
+                    "gemm_mxfp8:gemm --dtype mxfp8 --seconds 0.05 --no-telemetry" \
                     "hbm:hbm --bytes 2G --iters 2" "memtest:memtest --bytes 4G --patterns random,address"; do
         name=${target%%:*}; args=${target#*:}
+        case " ${PMC_TARGETS:-gemm_bf16 gemm_fp8 gemm_mxfp8 hbm memtest} " in *" $name "*) ;; *) continue ;; esac
         step "pmc_sq_$name" 120 timeout -s KILL 100 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_UNALIGNED_STALL \
           --output-format csv -d "$PWD/$OUT/pmc_sq_$name" -o p -- "$D" $args
         step "pmc_rd_$name" 120 timeout -s KILL 100 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$PWD/$OUT/pmc_rd_$name" -o p -- "$D" $args
         step "pmc_wr_$name" 120 timeout -s KILL 100 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$PWD/$OUT/pmc_wr_$name" -o p -- "$D" $args
+        for pass in sq rd wr; do
+          python scripts/prof_summary.py "$OUT/pmc_${pass}_$name" "$OUT/pmc_${pass}_$name.md" "$pass counters: gpumon-diag $name" > /dev/null
+        done
       done
       ;;
     *) echo "unknown step $s"; exit 2 ;;
