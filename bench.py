@@ -23,6 +23,7 @@ reductions, the JSON) on CPU tensors over gloo with toy sizes; it exists so the
 multi-rank path can be tested without GPUs and its output is labelled as such.
 """
 import argparse
+import http.client
 import json
 import os
 import re
@@ -48,6 +49,7 @@ class Sizes:
         self.coll_bytes = (1 << 20) if dry else (1 << 30)
 
 
+SCRAPE_ERRORS = (OSError, ValueError, http.client.HTTPException)  # what a dead or wedged exporter makes urllib raise
 EXPORTER_WINDOW_S = 10.0  # shortest window the exporter's CPU share is measured over
 
 
@@ -95,15 +97,21 @@ class ExporterChild:
             ok = False
         if ok:
             return total / 1e9
-        with open(f"/proc/{self.proc.pid}/stat") as f:
-            rest = f.read().rsplit(")", 1)[1].split()
+        try:
+            with open(f"/proc/{self.proc.pid}/stat") as f:
+                rest = f.read().rsplit(")", 1)[1].split()
+        except OSError:
+            return None  # the child is gone
         return (int(rest[11]) + int(rest[12])) / self.tck  # utime + stime
 
     def rss_kb(self):
-        with open(f"/proc/{self.proc.pid}/status") as f:
-            for line in f:
-                if line.startswith("VmRSS:"):
-                    return int(line.split()[1])
+        try:
+            with open(f"/proc/{self.proc.pid}/status") as f:
+                for line in f:
+                    if line.startswith("VmRSS:"):
+                        return int(line.split()[1])
+        except OSError:
+            pass
         return 0
 
     def scrape(self):
@@ -253,6 +261,7 @@ def main():
     ap.add_argument("--no-exporter", action="store_true", help="debug: skip the exporter child and the scrape phase")
     ap.add_argument("--prof-counters", action="store_true",
                     help="the exporter also programs the MFMA busy counter (rocprofiler-sdk device counting) on every GPU")
+    ap.add_argument("--kill-exporter-at", type=int, default=-1, help=argparse.SUPPRESS)  # test hook: SIGKILL the child before step N
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo + fake backend with toy sizes: control-flow test only")
     a = ap.parse_args()
 
@@ -340,7 +349,7 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
         phases += ["all_reduce", "all_gather", "all_to_all"]
     total_steps = a.warmup + a.steps
     ev = [[K.event() for _ in range(len(phases) + 1)] for _ in range(total_steps)]
-    scrape_ms, scrape_bytes = [], 0
+    scrape_ms, scrape_bytes, scrape_failures = [], 0, []
     memtest_errors = 0
 
     def step(i):
@@ -370,11 +379,21 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
             K.record(e[10])
             if i % 8 == 7:  # keep the all-reduced values bounded
                 ar.mul_(1.0 / world ** 8)
-        if exporter is not None:
-            ms, body = exporter.scrape()
-            if i >= a.warmup:
-                scrape_ms.append(ms)
-                scrape_bytes = len(body)
+        if exporter is not None and i == a.kill_exporter_at:
+            exporter.proc.kill()
+            exporter.proc.wait()
+        if exporter is not None and not scrape_failures:
+            # A monitoring process that dies or stops answering must not take the kernels' measurement with it: the
+            # first failure ends the scrape phase for the rest of the run and is reported in the JSON.
+            try:
+                ms, body = exporter.scrape()
+            except SCRAPE_ERRORS as e:
+                scrape_failures.append(f"step {i}: {e}"[-300:])
+                print(f"bench: scrape failed at step {i}: {e}", file=sys.stderr)
+            else:
+                if i >= a.warmup:
+                    scrape_ms.append(ms)
+                    scrape_bytes = len(body)
 
     def fence():
         K.sync()
@@ -399,10 +418,11 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
             time.sleep(min(1.0, max(0.0, EXPORTER_WINDOW_S - (time.perf_counter() - t_w0))))
             try:
                 exporter.scrape()
-            except OSError:
+            except SCRAPE_ERRORS:
                 break
         exporter_window_s = time.perf_counter() - t_w0
-        exporter_cpu_s = exporter.cpu_seconds() - cpu_w0
+        cpu_w1 = exporter.cpu_seconds()
+        exporter_cpu_s = cpu_w1 - cpu_w0 if cpu_w1 is not None and cpu_w0 is not None else None
     if world > 1:
         dist.barrier()  # the other ranks wait for rank 0's window before anything is torn down
 
@@ -455,15 +475,22 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
             "scrape_p99_ms": round(q[98], 3),
             "scrape_bytes": scrape_bytes,
             "scrapes": len(scrape_ms),
-            "exporter_cpu_percent_of_one_core": round(100.0 * exporter_cpu_s / max(exporter_window_s, 1e-9), 3),
+            "exporter_cpu_percent_of_one_core": None if exporter_cpu_s is None
+                                                else round(100.0 * exporter_cpu_s / max(exporter_window_s, 1e-9), 3),
             "exporter_cpu_window_s": round(exporter_window_s, 2),
             "exporter_rss_kb": exporter.rss_kb(),
             "exporter_interval_ms": 1000,
             "exporter_prof_counters": bool(a.prof_counters),
         })
-        m = re.search(rb'^dcgm_fi_prof_pipe_tensor_active\{gpu="0"[^}]*\} (\S+)', exporter.scrape()[1], re.M)
+        try:
+            m = re.search(rb'^dcgm_fi_prof_pipe_tensor_active\{gpu="0"[^}]*\} (\S+)', exporter.scrape()[1], re.M)
+        except SCRAPE_ERRORS:
+            m = None
         if m:
             extras["tensor_active_percent_gpu0_last_scrape"] = float(m.group(1))
+    if scrape_failures:
+        extras["scrape_error"] = scrape_failures[0]
+        extras["exporter_exit_code"] = exporter.proc.poll()
     if extras["memtest_errors"]:
         extras["FAILED"] = "memtest reported errors"
     gib = lambda b: f"{b / 2**30:g}GiB"  # noqa: E731

@@ -59,6 +59,17 @@ def test_multi_rank_dry_run_under_torchrun(n):
     assert x["scrapes"] == 5
 
 
+def test_a_dying_exporter_does_not_take_the_measurement_with_it():
+    """The monitoring child is killed before step 3 of 6: the kernels' numbers are still reported, the scrape phase ends at
+    the first failure and the JSON says so."""
+    r = subprocess.run([sys.executable, "bench.py", "--dry-run", "--steps", "6", "--warmup", "0", "--kill-exporter-at", "3"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    x = d["extras"]
+    assert d["value"] > 0 and x["scrapes"] == 3 and "step 3" in x["scrape_error"] and x["exporter_exit_code"] == -9
+
+
 def test_scrape_benchmark_on_eight_scripted_gpus(tmp_path):
     """The 8-GPU / 1 s operating point: p50 scrape under 50 ms, exporter under 1 % of a core."""
     out = tmp_path / "scrape.json"
