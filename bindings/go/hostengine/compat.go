@@ -7,3 +7,12 @@ type (
 	DcgmStatus   = Status
 	XIDErrorInfo = CriticalEvents
 )
+
+// The reference's policy condition names (bindings/go/dcgm/policy.go:23-31) for the conditions that carry an AMD
+// name here: double-bit ECC = uncorrectable ECC, retired pages = bad pages, NVLink = xGMI, XID = GPU event.
+const (
+	DbePolicy     = EccUePolicy
+	MaxRtPgPolicy = MaxBadPgPolicy
+	NvlinkPolicy  = XgmiPolicy
+	XidPolicy     = GpuEventPolicy
+)

@@ -10,7 +10,30 @@ import "C"
 // (the reference builds and tears down a group, a field group and a watch on every
 // GetDeviceStatus: bindings/go/dcgm/device_status.go:115-180).
 
+// PerfState is the driver's performance level, the P-state analog (bindings/go/dcgm/device_status.go:14-27);
+// the amdgpu driver has named levels instead of P0..P15.
 type PerfState uint
+
+const (
+	PerfStateAuto PerfState = iota
+	PerfStateLow
+	PerfStateHigh
+	PerfStateManual
+	PerfStateStableStd
+	PerfStateStablePeak
+	PerfStateStableMinMclk
+	PerfStateStableMinSclk
+	PerfStateDeterminism
+	PerfStateUnknown PerfState = 0x100
+)
+
+func (p PerfState) String() string {
+	names := []string{"auto", "low", "high", "manual", "stable_std", "stable_peak", "stable_min_mclk", "stable_min_sclk", "determinism"}
+	if int(p) < len(names) {
+		return names[p]
+	}
+	return "Unknown"
+}
 
 type UtilizationInfo struct {
 	GPU     *uint // %

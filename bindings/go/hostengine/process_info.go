@@ -29,10 +29,8 @@ type ProcessUtilInfo struct {
 	StartTime      Time
 	EndTime        Time
 	EnergyConsumed *float64 // J
-	GfxUtil        *float64 // % of the device, averaged over the process lifetime
-	MemUtil        *float64
-	ProcGfxUtil    *float64 // the process' own share of the gfx engine
-	ProcMemUtil    *float64
+	GfxUtil        *float64 // the process' own share of the gfx engine, % ("SmUtil" in the reference)
+	MemUtil        *float64 // the process' own share of the memory controllers, %
 }
 
 type PCIStats struct {
@@ -57,7 +55,7 @@ type ViolationTime struct {
 
 type CriticalEvents struct {
 	NumErrors int
-	TimeStamp []time.Time
+	Timestamp []time.Time
 }
 
 type ProcessInfo struct {
@@ -67,9 +65,10 @@ type ProcessInfo struct {
 	ProcessUtilization ProcessUtilInfo
 	PCI                PCIStats
 	Memory             MemoryStats
-	AvgClocks          ClockInfo
+	GpuUtilization     UtilizationInfo // of the whole device, averaged over the process lifetime (encoder / decoder stay nil)
+	Clocks             ClockInfo       // averages over the process lifetime
 	Violations         ViolationTime
-	Events             CriticalEvents // "XIDErrors" in the reference
+	XIDErrors          CriticalEvents // resets, RAS errors and VM faults while the process ran: the XID analog
 }
 
 func watchPidFields() (GroupHandle, error) {
@@ -102,8 +101,9 @@ func getProcessInfo(g GroupHandle, pid uint) ([]ProcessInfo, error) {
 		}
 		p := ProcessInfo{GPU: uint(s.gpu), PID: uint(s.pid), Name: C.GoString(&s.name[0])}
 		p.ProcessUtilization = ProcessUtilInfo{StartTime: Time(s.start_ts_us / 1000000), EndTime: Time(s.end_ts_us / 1000000),
-			GfxUtil: optFloat(s.gfx_util_avg, ok(1)), MemUtil: optFloat(s.mem_util_avg, ok(2)),
-			ProcGfxUtil: optFloat(s.proc_gfx_util_avg, ok(3)), ProcMemUtil: optFloat(s.proc_mem_util_avg, ok(4))}
+			GfxUtil: optFloat(s.proc_gfx_util_avg, ok(3)), MemUtil: optFloat(s.proc_mem_util_avg, ok(4))}
+		p.GpuUtilization = UtilizationInfo{GPU: optUint(C.int64_t(float64(s.gfx_util_avg)+0.5), ok(1)),
+			Memory: optUint(C.int64_t(float64(s.mem_util_avg)+0.5), ok(2))}
 		if ok(0) {
 			j := float64(s.energy_mj) / 1000
 			p.ProcessUtilization.EnergyConsumed = &j
@@ -112,13 +112,13 @@ func getProcessInfo(g GroupHandle, pid uint) ([]ProcessInfo, error) {
 			Replays: optInt(s.pcie_replays, ok(7))}
 		p.Memory = MemoryStats{GlobalUsed: optInt(s.max_vram_bytes, ok(8)),
 			ECCErrors: ECCErrorsInfo{Correctable: optUint(s.ecc_ce, ok(9)), Uncorrectable: optUint(s.ecc_ue, ok(10))}}
-		p.AvgClocks = ClockInfo{Cores: optUint(s.gfx_clock_avg, ok(11)), Memory: optUint(s.mem_clock_avg, ok(12))}
+		p.Clocks = ClockInfo{Cores: optUint(s.gfx_clock_avg, ok(11)), Memory: optUint(s.mem_clock_avg, ok(12))}
 		p.Violations = ViolationTime{Power: dur(s.power_violation_us, 13), Thermal: dur(s.thermal_violation_us, 14),
 			Reliability: dur(s.reliability_violation_us, 15), BoardLimit: dur(s.board_limit_violation_us, 16),
 			LowUtilization: dur(s.low_util_violation_us, 17), SyncBoost: dur(s.sync_boost_violation_us, 18)}
-		p.Events.NumErrors = int(s.num_critical_events)
+		p.XIDErrors.NumErrors = int(s.num_critical_events)
 		for k := 0; k < int(s.num_critical_events) && k < int(C.GM_MAX_EVENT_TS); k++ {
-			p.Events.TimeStamp = append(p.Events.TimeStamp, time.UnixMicro(int64(s.critical_event_ts_us[k])))
+			p.XIDErrors.Timestamp = append(p.XIDErrors.Timestamp, time.UnixMicro(int64(s.critical_event_ts_us[k])))
 		}
 		out = append(out, p)
 	}

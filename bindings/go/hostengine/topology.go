@@ -21,8 +21,15 @@ const (
 	P2PLinkXGMI
 )
 
-// PCIPaths is the long description of the link class.
-func (l P2PLinkType) PCIPaths() string { return C.GoString(C.gm_link_type_description(C.int32_t(l))) }
+// PCIPaths is the short code of the link class as a topology matrix prints it: PSB, PIX, PXB, PHB, NODE, SYS as in
+// the reference (bindings/go/dcgm/topology.go:31-56), XGMI where the reference has NV1..NV4 (P2PLink.Name adds the
+// hop count), N/A when unknown.
+func (l P2PLinkType) PCIPaths() string { return C.GoString(C.gm_link_type_name(C.int32_t(l), 0)) }
+
+// Description is the long form ("Connected through the xGMI fabric", "Single PCI switch", ...).
+func (l P2PLinkType) Description() string { return C.GoString(C.gm_link_type_description(C.int32_t(l))) }
+
+func (l P2PLinkType) String() string { return l.PCIPaths() }
 
 type P2PLink struct {
 	GPU      uint

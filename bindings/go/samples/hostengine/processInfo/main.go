@@ -68,13 +68,13 @@ func main() {
 		fmt.Printf("----------Performance Stats-------------------------------------------\n")
 		fmt.Printf("Energy Consumed              : %s\n", f(p.ProcessUtilization.EnergyConsumed, " J"))
 		fmt.Printf("Max HBM Used                 : %s\n", i(p.Memory.GlobalUsed, " B"))
-		fmt.Printf("Avg Gfx Clock                : %s\nAvg Memory Clock             : %s\n", u(p.AvgClocks.Cores, " MHz"), u(p.AvgClocks.Memory, " MHz"))
-		fmt.Printf("Avg Gfx Utilization          : %s\nAvg Memory Utilization       : %s\n", f(p.ProcessUtilization.GfxUtil, " %"), f(p.ProcessUtilization.MemUtil, " %"))
-		fmt.Printf("Process Gfx Share            : %s\n", f(p.ProcessUtilization.ProcGfxUtil, " %"))
+		fmt.Printf("Avg Gfx Clock                : %s\nAvg Memory Clock             : %s\n", u(p.Clocks.Cores, " MHz"), u(p.Clocks.Memory, " MHz"))
+		fmt.Printf("Avg Gfx Utilization          : %s\nAvg Memory Utilization       : %s\n", u(p.GpuUtilization.GPU, " %"), u(p.GpuUtilization.Memory, " %"))
+		fmt.Printf("Process Gfx Share            : %s\n", f(p.ProcessUtilization.GfxUtil, " %"))
 		fmt.Printf("Avg PCIe Rx / Tx             : %s / %s\n", i(p.PCI.AvgRxKBs, " KB/s"), i(p.PCI.AvgTxKBs, " KB/s"))
 		fmt.Printf("----------Event Stats-------------------------------------------------\n")
 		fmt.Printf("ECC Correctable / Uncorr.    : %s / %s\n", u(p.Memory.ECCErrors.Correctable, ""), u(p.Memory.ECCErrors.Uncorrectable, ""))
-		fmt.Printf("Critical Events              : %d %v\n", p.Events.NumErrors, p.Events.TimeStamp)
+		fmt.Printf("Critical Events              : %d %v\n", p.XIDErrors.NumErrors, p.XIDErrors.Timestamp)
 		fmt.Printf("----------Slowdown Stats----------------------------------------------\n")
 		fmt.Printf("Power / Thermal              : %s / %s\n", d(p.Violations.Power), d(p.Violations.Thermal))
 		fmt.Printf("Reliability / Board Limit    : %s / %s\n", d(p.Violations.Reliability), d(p.Violations.BoardLimit))

@@ -94,15 +94,53 @@ type ECCErrorsInfo struct {
 	Uncorrectable *uint64
 }
 
+// DeviceMemory and MemoryInfo nest like the reference's (nvml.go:239-247): st.Memory.Global.Used.
+type DeviceMemory struct {
+	Used *uint64 // MiB of HBM
+	Free *uint64 // MiB
+}
+
 type MemoryInfo struct {
-	Used      *uint64 // MiB
-	Free      *uint64 // MiB
+	Global    DeviceMemory
 	ECCErrors ECCErrorsInfo
 }
 
 type PCIThroughputInfo struct {
-	RX *uint // MB/s
+	RX *uint // MB/s; nil where the device library has no PCIe traffic counters
 	TX *uint
+}
+
+// PCIStatusInfo nests like the reference's (nvml.go:228-231): st.PCI.Throughput.RX.  VisibleVRAMUsed is
+// the BAR1Used analog: MiB in use of the CPU-visible aperture (all of HBM on a large-BAR MI355X).
+type PCIStatusInfo struct {
+	VisibleVRAMUsed *uint64
+	Throughput      PCIThroughputInfo
+	Replays         *uint64 // PCIe replay counter
+}
+
+// PerfState is the driver's performance level, the P-state analog (nvml.go:98-111).  The amdgpu driver has
+// named levels instead of P0..P15.
+type PerfState uint
+
+const (
+	PerfStateAuto PerfState = iota
+	PerfStateLow
+	PerfStateHigh
+	PerfStateManual
+	PerfStateStableStd
+	PerfStateStablePeak
+	PerfStateStableMinMclk
+	PerfStateStableMinSclk
+	PerfStateDeterminism
+	PerfStateUnknown PerfState = 0x100
+)
+
+func (p PerfState) String() string {
+	names := []string{"auto", "low", "high", "manual", "stable_std", "stable_peak", "stable_min_mclk", "stable_min_sclk", "determinism"}
+	if int(p) < len(names) {
+		return names[p]
+	}
+	return "Unknown"
 }
 
 // ProcessType keeps the reference's three kinds (nvml.go:113-131).  KFD processes are compute
@@ -141,10 +179,10 @@ type DeviceStatus struct {
 	Utilization UtilizationInfo
 	Memory      MemoryInfo
 	Clocks      ClockInfo
-	PCI         PCIThroughputInfo
+	PCI         PCIStatusInfo
 	Processes   []ProcessInfo
 	Throttle    *ThrottleReason
-	Performance *uint
+	Performance *PerfState
 	EnergyJ     *float64 // energy counter since driver load
 }
 
@@ -332,10 +370,14 @@ func (d *Device) Status() (*DeviceStatus, error) {
 	st.Utilization = UtilizationInfo{GPU: optUint(s.gfxUtil, ok(2)), Memory: optUint(s.memUtil, ok(3)),
 		Encoder: optUint(s.encUtil, ok(4)), Decoder: optUint(s.decUtil, ok(5))}
 	st.Clocks = ClockInfo{Cores: optUint(s.gfxClock, ok(6)), Memory: optUint(s.memClock, ok(7))}
-	st.PCI = PCIThroughputInfo{RX: optUint(s.pcieRxKB/1000, ok(9)), TX: optUint(s.pcieTxKB/1000, ok(10))}
-	st.Memory = MemoryInfo{Used: optU64(s.vramUsed, ok(12)), Free: optU64(s.vramFree, ok(13)),
+	st.PCI = PCIStatusInfo{VisibleVRAMUsed: optU64(s.visVramUsed, ok(8)), Replays: optU64(s.pcieReplays, ok(11)),
+		Throughput: PCIThroughputInfo{RX: optUint(s.pcieRxKB/1000, ok(9)), TX: optUint(s.pcieTxKB/1000, ok(10))}}
+	st.Memory = MemoryInfo{Global: DeviceMemory{Used: optU64(s.vramUsed, ok(12)), Free: optU64(s.vramFree, ok(13))},
 		ECCErrors: ECCErrorsInfo{Correctable: optU64(s.eccCE, ok(14)), Uncorrectable: optU64(s.eccUE, ok(15))}}
-	st.Performance = optUint(s.perfLevel, ok(16))
+	if ok(16) {
+		ps := PerfState(s.perfLevel)
+		st.Performance = &ps
+	}
 	if ok(18) {
 		t := ThrottleReason(s.throttle)
 		st.Throttle = &t
