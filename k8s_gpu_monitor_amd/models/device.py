@@ -122,6 +122,16 @@ class DeviceStatus:
     THROTTLE_NAMES = {1: "Power cap", 2: "Thermal", 4: "HBM thermal", 8: "VR thermal", 16: "PROCHOT",
                       32: "Low utilization", 64: "Host limit"}
 
+    PERF_LEVEL_NAMES = ("auto", "low", "high", "manual", "stable_std", "stable_peak", "stable_min_mclk", "stable_min_sclk",
+                        "determinism")
+
+    def performance_name(self) -> str:
+        """The driver's performance level by name: the counterpart of PerfState.String() (bindings/go/nvml/nvml.go:106-111),
+        which prints P0..P15; the amdgpu driver has named levels."""
+        if self.performance is None or not 0 <= self.performance < len(self.PERF_LEVEL_NAMES):
+            return "Unknown"
+        return self.PERF_LEVEL_NAMES[self.performance]
+
     def throttle_reasons(self) -> List[str]:
         if not self.throttle:
             return ["No clocks throttling"] if self.throttle == 0 else []

@@ -228,6 +228,8 @@ def test_device_status_and_models(engine):
     st = d.status()
     assert st.utilization.gpu == 80 and st.utilization.encoder is None
     assert st.throttle_reasons() == ["No clocks throttling"]
+    assert st.performance_name() in st.PERF_LEVEL_NAMES + ("Unknown",)
+    assert (st.performance is None) == (st.performance_name() == "Unknown")
     assert E.device_mode(6)["compute_partition"] == "SPX"
 
 
