@@ -23,6 +23,8 @@
 //   --resource NAMES device-plugin resource names (default amd.com/gpu)
 //   --diag-results PATH   export the report(s) left by `gpumon-diag --publish` as gpumon_diag_* metrics
 //   --state-file PATH     keep the gpu_last_not_idle_time latch across restarts
+//   --health         health check of every exported GPU on each sweep: gpumon_health_status{system=...},
+//                    gpumon_health_overall, gpumon_health_incidents_total{system=...,level=...}
 //   --legacy-layout  GPU-major output exactly like the reference's awk program
 //   --once           one sweep, then exit
 //   -connect ADDR [-socket]   use a running gpumon-hostengine instead of -e
@@ -55,7 +57,7 @@ int main(int argc, char** argv) {
     usage(argv[0]);
     return 1;
   }
-  bool embedded = false, profiling = false, once = false, extras = false, self = false, rest = false, legacy = false;
+  bool embedded = false, profiling = false, once = false, extras = false, self = false, rest = false, legacy = false, health = false;
   std::string out = "/run/prometheus/dcgm.prom", listen, gpus, kubelet, podmap, resource, diagres, statefile;
   long interval = 1000;
   for (size_t i = 0; i < args.size(); i++) {
@@ -87,6 +89,7 @@ int main(int argc, char** argv) {
     else if (a == "--diag-results") val(&diagres);
     else if (a == "--state-file") val(&statefile);
     else if (a == "--legacy-layout") legacy = true;
+    else if (a == "--health") health = true;
     else if (a == "--once") once = true;
     else { usage(argv[0]); return 1; }
   }
@@ -133,6 +136,7 @@ int main(int argc, char** argv) {
   cfg.self_metrics = self;
   cfg.rest_api = rest;
   cfg.legacy_layout = legacy;
+  cfg.health = health;
   cfg.interval_ms = interval;
   cfg.gpus = gpus.c_str();
   cfg.output_path = out.empty() ? nullptr : out.c_str();

@@ -730,6 +730,7 @@ gm_status_t gm_exporter_create(const gm_exporter_config_t* c, gm_exporter_t* out
   if (c->pod_map_path) cfg.pod_map_path = c->pod_map_path;
   if (c->diag_results_path) cfg.diag_results_path = c->diag_results_path;
   if (c->state_path) cfg.state_path = c->state_path;
+  cfg.health = c->health != 0;
   auto ex = std::make_shared<Exporter>(e, cfg);
   gm_status_t st = ex->init();
   if (st != GM_ST_OK) return st;

@@ -175,6 +175,11 @@ gm_status_t Exporter::init() {
   if (st != GM_ST_OK) return st;
   watching_ = true;
   if (cfg_.self_metrics) engine_->introspect_toggle(true);
+  if (cfg_.health) {
+    if ((st = engine_->health_set(group_, GM_HEALTH_WATCH_ALL)) != GM_ST_OK) return st;
+    health_.assign(gpus_.size(), {});
+    health_overall_.assign(gpus_.size(), GM_HEALTH_PASS);
+  }
   if (!cfg_.pod_map_path.empty() || !cfg_.kubelet_socket.empty()) refresh_pod_map();
   load_state();
   return GM_ST_OK;
@@ -366,9 +371,63 @@ void Exporter::render(std::string* out) {
           if (!emit_sample(fam, m, g) && g == 0 && out->size() == after_header) out->resize(mark);
         }
   }
+  if (cfg_.health && health_valid_) render_health(base, podl, out);
   if (cfg_.self_metrics) render_self(out);
   if (!cfg_.diag_results_path.empty()) render_diag_results(cfg_.diag_results_path, out, engine_);
   last_render_us_ = monotonic_us() - t0;
+}
+
+// One health check per sweep (not per scrape: the checks that look at the growth of a counter compare with the
+// previous check, and a scraper must not shorten that window).
+void Exporter::check_health() {
+  std::vector<gm_health_response_t> rs;
+  gm_status_t st = engine_->health_check(group_, &rs);
+  std::lock_guard<std::mutex> l(mu_);
+  if (st != GM_ST_OK) {
+    health_valid_ = false;
+    return;
+  }
+  for (auto& r : rs) {
+    auto it = std::find(gpus_.begin(), gpus_.end(), r.gpu);
+    if (it == gpus_.end()) continue;
+    const size_t g = (size_t)(it - gpus_.begin());
+    for (auto& c : health_[g]) c.level = GM_HEALTH_PASS;
+    health_overall_[g] = r.overall;
+    for (uint32_t i = 0; i < r.incident_count && i < GM_MAX_INCIDENTS; i++) {
+      const gm_incident_t& in = r.incidents[i];
+      for (int b = 0; b < kHealthSystems; b++) {
+        if (in.system != (1u << b)) continue;
+        HealthCell& c = health_[g][(size_t)b];
+        c.level = std::max(c.level, in.health);
+        if (in.health >= GM_HEALTH_FAIL) c.failures++;
+        else if (in.health >= GM_HEALTH_WARN) c.warnings++;
+      }
+    }
+  }
+  health_valid_ = true;
+}
+
+void Exporter::render_health(const std::vector<std::string>& base, const std::vector<std::string>& podl, std::string* out) {
+  static const char* kSystem[kHealthSystems] = {"pcie", "xgmi", "memory", "compute", "thermal", "power", "driver", "firmware"};
+  *out += "# HELP gpumon_health_status Result of the engine's health check per GPU subsystem (0 = pass, 10 = warning, 20 = failure).\n"
+          "# TYPE gpumon_health_status gauge\n";
+  for (size_t g = 0; g < gpus_.size(); g++)
+    for (int b = 0; b < kHealthSystems; b++)
+      *out += strprintf("gpumon_health_status%s,system=\"%s\"%s} %d\n", base[g].c_str(), kSystem[b], podl[g].c_str(), health_[g][(size_t)b].level);
+  *out += "# HELP gpumon_health_overall Worst subsystem result of the GPU's last health check (0 = pass, 10 = warning, 20 = failure).\n"
+          "# TYPE gpumon_health_overall gauge\n";
+  for (size_t g = 0; g < gpus_.size(); g++)
+    *out += strprintf("gpumon_health_overall%s%s} %d\n", base[g].c_str(), podl[g].c_str(), health_overall_[g]);
+  *out += "# HELP gpumon_health_incidents_total Health incidents reported since the exporter started, by subsystem and level.\n"
+          "# TYPE gpumon_health_incidents_total counter\n";
+  for (size_t g = 0; g < gpus_.size(); g++)
+    for (int b = 0; b < kHealthSystems; b++) {
+      const HealthCell& c = health_[g][(size_t)b];
+      *out += strprintf("gpumon_health_incidents_total%s,system=\"%s\",level=\"warning\"%s} %llu\n", base[g].c_str(), kSystem[b],
+                        podl[g].c_str(), (unsigned long long)c.warnings);
+      *out += strprintf("gpumon_health_incidents_total%s,system=\"%s\",level=\"failure\"%s} %llu\n", base[g].c_str(), kSystem[b],
+                        podl[g].c_str(), (unsigned long long)c.failures);
+    }
 }
 
 void Exporter::render_self(std::string* out) {
@@ -392,6 +451,7 @@ void Exporter::render_self(std::string* out) {
 }
 
 gm_status_t Exporter::publish() {
+  if (cfg_.health) check_health();
   std::string text;
   render(&text);
   if (!cfg_.output_path.empty()) {

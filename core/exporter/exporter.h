@@ -6,6 +6,7 @@
 // (exporters/prometheus-dcgm/k8s/pod-gpu-metrics-exporter/src/device_pod.go:57-113).
 #pragma once
 
+#include <array>
 #include <atomic>
 #include <condition_variable>
 #include <map>
@@ -42,6 +43,7 @@ struct ExporterConfig {
   bool self_metrics = false;
   bool rest_api = false;
   bool legacy_layout = false;
+  bool health = false;  // health check of every exported GPU once per sweep, exported as gpumon_health_*
   int64_t interval_ms = 1000;
   std::string gpus;  // "" / "-1" = all
   std::string output_path;
@@ -72,6 +74,8 @@ class Exporter {
   void refresh_pod_map();
   void handle_http(const HttpRequest& req, HttpResponse* resp);
   void render_self(std::string* out);
+  void check_health();
+  void render_health(const std::vector<std::string>& base, const std::vector<std::string>& podl, std::string* out);
   void load_state();
   void save_state(bool force);
 
@@ -91,6 +95,17 @@ class Exporter {
   bool state_dirty_ = false;
   int64_t state_saved_mono_ = 0;
   PodMap pod_map_;
+  // Health of every exported GPU as of the last sweep (under mu_): level per subsystem bit, and how many warnings and
+  // failures each subsystem has reported since the exporter started (an incident that lasts one check is still seen
+  // by a scraper that looks at the counter's increase).
+  struct HealthCell {
+    int32_t level = 0;
+    uint64_t warnings = 0, failures = 0;
+  };
+  static constexpr int kHealthSystems = 8;
+  std::vector<std::array<HealthCell, kHealthSystems>> health_;
+  std::vector<int32_t> health_overall_;
+  bool health_valid_ = false;
   std::string cached_;  // last published text (served over HTTP between sweeps)
   std::vector<gm_value_t> scratch_;
 

@@ -735,8 +735,9 @@ typedef struct {
   const char* diag_results_path; /* gpumon-diag --publish report (file, or directory of *.json): exported as gpumon_diag_* */
   const char* state_path;   /* NULL = none; file that carries what the exporter itself accumulates (the
                                gpu_last_not_idle_time latch, per GPU UUID) across restarts */
+  int32_t health;           /* run the engine's health check on every sweep: gpumon_health_* families */
 } gm_exporter_config_t;
-#define GM_EXPORTER_CONFIG_VERSION GM_VERSION(gm_exporter_config_t, 3)
+#define GM_EXPORTER_CONFIG_VERSION GM_VERSION(gm_exporter_config_t, 4)
 
 typedef uint32_t gm_exporter_t;
 GM_API gm_status_t gm_exporter_create(const gm_exporter_config_t* cfg, gm_exporter_t* out);

@@ -260,8 +260,9 @@ class ExporterConfig(C.Structure):
                 ("self_metrics", C.c_int32), ("interval_ms", C.c_int64), ("gpus", C.c_char_p),
                 ("output_path", C.c_char_p), ("listen", C.c_char_p), ("kubelet_socket", C.c_char_p),
                 ("resource_names", C.c_char_p), ("pod_map_path", C.c_char_p), ("rest_api", C.c_int32),
-                ("legacy_layout", C.c_int32), ("diag_results_path", C.c_char_p), ("state_path", C.c_char_p)]
-    VERSION = 3
+                ("legacy_layout", C.c_int32), ("diag_results_path", C.c_char_p), ("state_path", C.c_char_p),
+                ("health", C.c_int32)]
+    VERSION = 4
 
 
 class PodExporterConfig(C.Structure):

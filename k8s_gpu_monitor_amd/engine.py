@@ -404,11 +404,11 @@ class EventSet:
 class Exporter:
     def __init__(self, interval_ms=1000, gpus=None, output_path=None, listen=None, profiling=False, extras=False,
                  self_metrics=False, rest_api=False, legacy_layout=False, kubelet_socket=None, pod_map_path=None,
-                 resource_names=None, diag_results_path=None, state_path=None):
+                 resource_names=None, diag_results_path=None, state_path=None, health=False):
         c = A.versioned(A.ExporterConfig)
         c.interval_ms = interval_ms
         c.profiling, c.amd_extras, c.self_metrics = int(profiling), int(extras), int(self_metrics)
-        c.rest_api, c.legacy_layout = int(rest_api), int(legacy_layout)
+        c.rest_api, c.legacy_layout, c.health = int(rest_api), int(legacy_layout), int(health)
         self._keep = [_b(x) for x in (gpus, output_path, listen, kubelet_socket, resource_names, pod_map_path,
                                       diag_results_path, state_path)]
         (c.gpus, c.output_path, c.listen, c.kubelet_socket, c.resource_names, c.pod_map_path,

@@ -89,3 +89,33 @@ def test_systemd_units_reference_installed_binaries():
     # the flags of the unit files parse: --help style dry run is not available, so check against the usage text
     mk = open(os.path.join(DEPLOY, "bare-metal/Makefile")).read()
     assert "gpumon-hostengine" in mk and "systemctl enable --now" in mk
+
+
+def test_alert_rules_only_name_families_the_exporter_produces(tmp_path):
+    """Every metric an alert expression reads exists: in the exporter's output on the scripted backend with the flags
+    the deployments pass, or among the diagnostics families of core/exporter/diag_results.cc."""
+    rules_path = os.path.join(DEPLOY, "docker", "prometheus", "gpumon-alerts.yml")
+    rules = yaml.safe_load(open(rules_path))
+    alerts = [r for g in rules["groups"] for r in g["rules"]]
+    assert len(alerts) >= 15 and len({r["alert"] for r in alerts}) == len(alerts)
+    assert all(r["labels"]["severity"] in ("warning", "critical") and "summary" in r["annotations"] for r in alerts)
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=2")
+    r = subprocess.run([bin_path("gpumon-exporter"), "-e", "-p", "--health", "--extras", "--self-metrics", "--once", "-o", ""], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    produced = set(re.findall(r"^# TYPE (\w+) ", r.stdout, re.M))
+    # the diagnostics families come from a report file, not from the backend: their names are read from the source
+    produced |= set(re.findall(r'"(gpumon_diag_\w+)"', open(os.path.join(ROOT, "core", "exporter", "diag_results.cc")).read()))
+    functions = {"increase", "rate", "changes", "time", "timestamp", "and", "or", "for", "level", "failure"}
+    for a in alerts:
+        names = set(re.findall(r"\b([a-z_][a-z0-9_]*)\b", re.sub(r'"[^"]*"', "", a["expr"]))) - functions
+        names = {n for n in names if not re.fullmatch(r"\d+[smh]", n)}
+        assert names and names <= produced, (a["alert"], sorted(names - produced))
+    # the Prometheus configurations load the file, and the Kubernetes ConfigMap carries the same rules
+    prom = yaml.safe_load(open(os.path.join(DEPLOY, "docker", "prometheus", "prometheus.yml")))
+    assert prom["rule_files"] == ["/etc/prometheus/gpumon-alerts.yml"]
+    assert "gpumon-alerts.yml" in open(os.path.join(DEPLOY, "docker", "prometheus", "Dockerfile")).read()
+    cm = yaml.safe_load(open(os.path.join(DEPLOY, "k8s", "pod-gpu-metrics-exporter", "prometheus", "prometheus-alerts-configmap.yaml")))
+    assert yaml.safe_load(cm["data"]["gpumon-alerts.yml"]) == rules
+    k8s_prom = yaml.safe_load(open(os.path.join(DEPLOY, "k8s", "pod-gpu-metrics-exporter", "prometheus", "prometheus-configmap.yaml")))
+    assert yaml.safe_load(k8s_prom["data"]["prometheus.yml"])["rule_files"] == ["/etc/prometheus/rules/gpumon-alerts.yml"]

@@ -448,3 +448,42 @@ def test_exporter_cli_diag_results_flag(tmp_path):
                         "--diag-results", str(rep)], env=env, capture_output=True, text=True, timeout=30)
     assert r.returncode == 0, r.stderr
     assert 'gpumon_diag_pass{gpu="0"} 1' in out.read_text()
+
+
+def test_health_families_follow_the_engine_health_check(engine2):
+    """--health: one health check per sweep, exported per subsystem; an incident that is gone at the next sweep stays
+    visible in the incident counter."""
+    def sample(fams, name, **want):
+        hits = [v for l, v in fams[name].samples if all(l.get(k) == x for k, x in want.items())]
+        assert len(hits) == 1, (name, want, hits)
+        return hits[0]
+
+    with E.Exporter(health=True, kubelet_socket=None) as ex:
+        ex.sweep()
+        f = parse(ex.render())
+        assert len(f["gpumon_health_status"].samples) == 2 * 8 and f["gpumon_health_incidents_total"].type == "counter"
+        assert all(v == 0 for _l, v in f["gpumon_health_status"].samples + f["gpumon_health_overall"].samples)
+        E.fake_ctl("set gpu=1 field=150 value=104")  # hot: thermal warning
+        E.fake_ctl("link_down gpu=0 link=0")          # xGMI link down: failure
+        time.sleep(1.1)
+        ex.sweep()
+        f = parse(ex.render())
+        assert sample(f, "gpumon_health_status", gpu="1", system="thermal") == 10
+        assert sample(f, "gpumon_health_status", gpu="0", system="xgmi") == 20
+        assert sample(f, "gpumon_health_status", gpu="0", system="thermal") == 0
+        assert sample(f, "gpumon_health_overall", gpu="0") == 20 and sample(f, "gpumon_health_overall", gpu="1") == 10
+        assert sample(f, "gpumon_health_incidents_total", gpu="1", system="thermal", level="warning") == 1
+        assert sample(f, "gpumon_health_incidents_total", gpu="0", system="xgmi", level="failure") >= 1
+        # a scrape between two sweeps renders the same verdicts and does not run a check of its own
+        assert parse(ex.render())["gpumon_health_incidents_total"].samples == f["gpumon_health_incidents_total"].samples
+        E.fake_ctl("set gpu=1 field=150 value=60")
+        E.fake_ctl("link_up gpu=0 link=0")
+        time.sleep(1.1)
+        ex.sweep()
+        f = parse(ex.render())
+        assert sample(f, "gpumon_health_status", gpu="1", system="thermal") == 0
+        assert sample(f, "gpumon_health_overall", gpu="0") == 0
+        assert sample(f, "gpumon_health_incidents_total", gpu="1", system="thermal", level="warning") == 1  # the counter keeps it
+    with E.Exporter() as ex:  # off by default: the contract output is unchanged
+        ex.sweep()
+        assert "gpumon_health_status" not in parse(ex.render())
