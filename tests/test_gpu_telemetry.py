@@ -129,6 +129,25 @@ def test_exporter_scrape_latency_and_format(hw):
         assert any(k.startswith("gpumon_xgmi") for k in fam)
 
 
+def test_health_families_on_the_real_device(hw):
+    """--health on the device library: eight subsystem verdicts per GPU; a healthy idle part reports no failure, and
+    the verdicts agree with the engine's own health check."""
+    n = E.device_count()
+    with E.Exporter(interval_ms=1000, health=True) as ex:
+        ex.sweep()
+        time.sleep(1.1)
+        ex.sweep()  # the second check has a baseline for the counters it compares
+        fam = promparse.parse(ex.render())
+    status = fam["gpumon_health_status"].samples
+    assert len(status) == 8 * n and {l["system"] for l, _v in status} == {"pcie", "xgmi", "memory", "compute", "thermal", "power",
+                                                                            "driver", "firmware"}
+    assert all(v in (0, 10, 20) for _l, v in status)
+    overall = {l["gpu"]: v for l, v in fam["gpumon_health_overall"].samples}
+    assert len(overall) == n and all(v == max(x for l, x in status if l["gpu"] == g) for g, v in overall.items())
+    assert all(v < 20 for v in overall.values()), status  # a failing subsystem on the test box would be worth knowing about
+    assert len(fam["gpumon_health_incidents_total"].samples) == 16 * n
+
+
 def test_sampling_overhead_is_small(hw):
     """EVERY field of the registry on every GPU at 10 Hz — ten times the production rate — for 3 s."""
     ids = E.field_list()
