@@ -101,6 +101,7 @@ Exporter::Exporter(Engine* engine, const ExporterConfig& cfg) : engine_(engine),
 Exporter::~Exporter() {
   stop();
   save_state(true);
+  if (policy_registered_) engine_->policy_unregister(policy_reg_);  // before the members the callback touches go away
   if (watching_) {
     engine_->unwatch_fields(group_, fg_);
     engine_->field_group_destroy(fg_);
@@ -179,6 +180,16 @@ gm_status_t Exporter::init() {
     if ((st = engine_->health_set(group_, GM_HEALTH_WATCH_ALL)) != GM_ST_OK) return st;
     health_.assign(gpus_.size(), {});
     health_overall_.assign(gpus_.size(), GM_HEALTH_PASS);
+    violations_.assign(gpus_.size(), {});
+    st = engine_->policy_register(group_, GM_POLICY_COND_ALL, [this](const gm_violation_t& v) {
+      auto it = std::find(gpus_.begin(), gpus_.end(), v.gpu);
+      if (it == gpus_.end()) return;
+      std::lock_guard<std::mutex> l(violation_mu_);
+      for (int b = 0; b < kPolicyConditions; b++)
+        if (v.condition == (1u << b)) violations_[(size_t)(it - gpus_.begin())][(size_t)b]++;
+    }, &policy_reg_);
+    if (st != GM_ST_OK) return st;
+    policy_registered_ = true;
   }
   if (!cfg_.pod_map_path.empty() || !cfg_.kubelet_socket.empty()) refresh_pod_map();
   load_state();
@@ -428,6 +439,14 @@ void Exporter::render_health(const std::vector<std::string>& base, const std::ve
       *out += strprintf("gpumon_health_incidents_total%s,system=\"%s\",level=\"failure\"%s} %llu\n", base[g].c_str(), kSystem[b],
                         podl[g].c_str(), (unsigned long long)c.failures);
     }
+  static const char* kCondition[kPolicyConditions] = {"ecc_ue", "pcie", "bad_pages", "thermal", "power", "xgmi", "gpu_event"};
+  *out += "# HELP gpumon_policy_violations_total Policy violations since the exporter started, by condition.\n"
+          "# TYPE gpumon_policy_violations_total counter\n";
+  std::lock_guard<std::mutex> l(violation_mu_);
+  for (size_t g = 0; g < gpus_.size(); g++)
+    for (int b = 0; b < kPolicyConditions; b++)
+      *out += strprintf("gpumon_policy_violations_total%s,condition=\"%s\"%s} %llu\n", base[g].c_str(), kCondition[b], podl[g].c_str(),
+                        (unsigned long long)violations_[g][(size_t)b]);
 }
 
 void Exporter::render_self(std::string* out) {

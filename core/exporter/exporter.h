@@ -106,6 +106,13 @@ class Exporter {
   std::vector<std::array<HealthCell, kHealthSystems>> health_;
   std::vector<int32_t> health_overall_;
   bool health_valid_ = false;
+  // Policy violations of the exported GPUs since the exporter started, per condition bit (default thresholds, or the
+  // ones set on the engine); counted on the engine's notifier thread.
+  static constexpr int kPolicyConditions = 7;
+  std::mutex violation_mu_;
+  std::vector<std::array<uint64_t, kPolicyConditions>> violations_;
+  gm_policy_reg_t policy_reg_ = 0;
+  bool policy_registered_ = false;
   std::string cached_;  // last published text (served over HTTP between sweeps)
   std::vector<gm_value_t> scratch_;
 

@@ -121,6 +121,7 @@ static void test_concurrent_engine() {
     c.version = GM_EXPORTER_CONFIG_VERSION;
     c.interval_ms = 100;
     c.profiling = c.amd_extras = c.self_metrics = 1;
+    c.health = 1;  // health verdicts per sweep and violation counts from the notifier thread, next to the renders
     // a diagnostics report that is rewritten while it is being exported, and a state file
     char report[64], state[64];
     snprintf(report, sizeof report, "/tmp/gpumon-test-%d-diag.json", (int)getpid());
@@ -141,9 +142,15 @@ static void test_concurrent_engine() {
     OK(gm_exporter_create(&c, &ex));
     std::vector<char> buf(1 << 20);
     int round = 0;
+    OK(gm_exporter_sweep(ex));
     while (!stop) {
       size_t len = buf.size();
+      if (round % 10 == 0) {
+        gm_status_t sw = gm_exporter_sweep(ex);  // the injector fails whole GPUs now and then
+        CHECK(sw == GM_ST_OK || sw == GM_ST_GENERIC_ERROR || sw == GM_ST_STALE_DATA);
+      }
       OK(gm_exporter_render(ex, buf.data(), &len));
+      CHECK(strstr(buf.data(), "gpumon_health_overall{gpu=\"0\"") && strstr(buf.data(), "gpumon_policy_violations_total{gpu=\"7\""));
       CHECK(len > 1000 && strstr(buf.data(), "# TYPE dcgm_gpu_temp gauge"));  // single GPUs may be blanked by the injector
       CHECK(strstr(buf.data(), "gpumon_diag_memtest_errors{gpu=\"3\"}"));
       if (++round % 50 == 0) write_report(round % 100 == 0);
