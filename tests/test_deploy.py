@@ -3,6 +3,7 @@ flags they pass are flags the tools accept, ports / paths / scrape intervals are
 the contract values (exporters/prometheus-dcgm/k8s/*.yaml, docker/*, bare-metal/*
 of the reference, re-targeted at AMD device nodes)."""
 import glob
+import json
 import os
 import re
 import subprocess
@@ -119,3 +120,27 @@ def test_alert_rules_only_name_families_the_exporter_produces(tmp_path):
     assert yaml.safe_load(cm["data"]["gpumon-alerts.yml"]) == rules
     k8s_prom = yaml.safe_load(open(os.path.join(DEPLOY, "k8s", "pod-gpu-metrics-exporter", "prometheus", "prometheus-configmap.yaml")))
     assert yaml.safe_load(k8s_prom["data"]["prometheus.yml"])["rule_files"] == ["/etc/prometheus/rules/gpumon-alerts.yml"]
+
+
+def test_grafana_dashboard_queries_families_the_exporter_produces():
+    dash = json.load(open(os.path.join(DEPLOY, "docker", "grafana", "dashboards", "gpumon-node.json")))
+    assert dash["uid"] and len(dash["panels"]) >= 12 and len({p["id"] for p in dash["panels"]}) == len(dash["panels"])
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=2")
+    r = subprocess.run([bin_path("gpumon-exporter"), "-e", "-p", "--health", "--extras", "--self-metrics", "--once", "-o", ""], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    produced = set(re.findall(r"^# TYPE (\w+) ", r.stdout, re.M))
+    produced |= set(re.findall(r'"(gpumon_diag_\w+)"', open(os.path.join(ROOT, "core", "exporter", "diag_results.cc")).read()))
+    queried = set()
+    for p in dash["panels"]:
+        assert p["datasource"]["uid"] == "prometheus" and p["targets"]
+        for t in p["targets"]:
+            queried |= set(re.findall(r"\b((?:dcgm|gpumon)_\w+)", t["expr"]))
+    assert len(queried) >= 20 and queried <= produced, sorted(queried - produced)
+    # the compose stack provisions the data source the panels name, and mounts the dashboard directory
+    ds = yaml.safe_load(open(os.path.join(DEPLOY, "docker", "grafana", "provisioning", "datasources", "prometheus.yml")))
+    assert ds["datasources"][0]["uid"] == "prometheus"
+    compose = yaml.safe_load(open(os.path.join(DEPLOY, "docker", "docker-compose.yml")))
+    mounts = compose["services"]["grafana"]["volumes"]
+    assert any(m.startswith("./grafana/dashboards:") for m in mounts) and any(m.startswith("./grafana/provisioning:") for m in mounts)
+    assert compose["services"]["gpumon_exporter"]["command"] == ["--health", "--extras", "--self-metrics"]
