@@ -144,3 +144,36 @@ def test_grafana_dashboard_queries_families_the_exporter_produces():
     mounts = compose["services"]["grafana"]["volumes"]
     assert any(m.startswith("./grafana/dashboards:") for m in mounts) and any(m.startswith("./grafana/provisioning:") for m in mounts)
     assert compose["services"]["gpumon_exporter"]["command"] == ["--health", "--extras", "--self-metrics"]
+
+
+def test_one_listener_per_port_in_every_pod(tmp_path):
+    """Containers of a pod share a network namespace: where the pod exporter serves :9400, the node exporter image
+    (whose entrypoint also listens on :9400) must be told not to, and the flags it is given must be accepted."""
+    ep = _entrypoint("gpumon-exporter.Dockerfile")
+    assert ep[-2:] == ["--listen", ":9400"]
+    checked = 0
+    for path in sorted(glob.glob(os.path.join(DEPLOY, "k8s", "**", "*.yaml"), recursive=True)):
+        for doc in yaml.safe_load_all(open(path)):
+            if not doc or doc.get("kind") != "DaemonSet":
+                continue
+            containers = doc["spec"]["template"]["spec"]["containers"]
+            images = {c["image"].split(":")[0]: c for c in containers}
+            if "gpumon/exporter" not in images:
+                continue
+            args = ep[1:] + images["gpumon/exporter"].get("args", [])
+            listen = [args[i + 1] for i, a in enumerate(args) if a == "--listen"][-1]  # the last one wins
+            if "gpumon/pod-exporter" in images:
+                assert listen == "", path
+            # the whole command line parses and produces a file
+            out = tmp_path / f"{checked}.prom"
+            argv = [a for a in args]
+            if "-o" in argv:
+                argv[argv.index("-o") + 1] = str(out)
+            else:
+                argv += ["-o", str(out)]
+            argv = [a if a != ":9400" else "127.0.0.1:0" for a in argv]
+            env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=2")
+            r = subprocess.run([bin_path("gpumon-exporter"), *argv, "--once"], env=env, capture_output=True, text=True, timeout=60)
+            assert r.returncode == 0 and "gpumon_health_overall" in out.read_text(), (path, r.stderr)
+            checked += 1
+    assert checked == 4
