@@ -15,7 +15,8 @@ RUN make -j"$(nproc)" all prof
 
 FROM rocm/dev-ubuntu-22.04:7.2
 COPY --from=build /src/build/libgpumon.so /src/build/libgpumon_prof.so /usr/local/lib/
-COPY --from=build /src/build/bin/gpumon /src/build/bin/gpumon-exporter /src/build/bin/gpumon-hostengine /usr/local/bin/
+# gpumon-prof-probe is what --prof-counters=child starts (found next to the library: ../bin)
+COPY --from=build /src/build/bin/gpumon /src/build/bin/gpumon-exporter /src/build/bin/gpumon-hostengine /src/build/bin/gpumon-prof-probe /usr/local/bin/
 RUN ldconfig
 VOLUME /run/prometheus
 EXPOSE 9400
