@@ -56,7 +56,7 @@ EXPORTER_WINDOW_S = 10.0  # shortest window the exporter's CPU share is measured
 class ExporterChild:
     """gpumon-exporter as a child process (started before this process touches the GPU)."""
 
-    def __init__(self, backend="amdsmi", prof_counters=False, interval_ms=1000):
+    def __init__(self, backend="amdsmi", prof_counters=False, interval_ms=1000, extra_args=()):
         from k8s_gpu_monitor_amd._lib import binary
         env = dict(os.environ, GPUMON_BACKEND=backend)
         if prof_counters:  # MFMA pipe activity from hardware counters (libgpumon_prof.so inside the exporter)
@@ -65,7 +65,7 @@ class ExporterChild:
             env.setdefault("GPUMON_BACKEND_SPEC", "gpus=8,seed=1")
         self.proc = subprocess.Popen(
             [binary("gpumon-exporter"), "-e", "-p", "-o", "", "-d", str(int(interval_ms)), "--extras", "--self-metrics", "--listen",
-             "127.0.0.1:0"], stderr=subprocess.PIPE, text=True, env=env)
+             "127.0.0.1:0", *extra_args], stderr=subprocess.PIPE, text=True, env=env)
         self.port = None
         self.log = []
         deadline = time.time() + 60

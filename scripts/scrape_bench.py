@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--scrape-hz", type=float, default=1.0)
     ap.add_argument("--replicate", type=int, default=0, help="present every device of the backend N times")
     ap.add_argument("--interval-ms", type=int, default=1000, help="exporter sampling interval (its floor is 100)")
+    ap.add_argument("--health", action="store_true", help="the exporter also runs the health check and counts policy violations")
     ap.add_argument("--out")
     a = ap.parse_args()
 
@@ -54,7 +55,7 @@ def main():
         spec.append(f"replicate={a.replicate}")
     if spec:
         os.environ["GPUMON_BACKEND_SPEC"] = ",".join(spec)
-    ex = ExporterChild(a.backend, interval_ms=a.interval_ms)
+    ex = ExporterChild(a.backend, interval_ms=a.interval_ms, extra_args=["--health"] if a.health else [])
     try:
         time.sleep(1.5)  # first sweep done, static attributes cached
         ex.scrape()
@@ -74,7 +75,7 @@ def main():
         gpus = len({l.get("gpu") for l, _ in fams["dcgm_sm_clock"].samples})
         self_metrics = {n: f.samples[0][1] for n, f in fams.items() if n.startswith("gpumon_") and len(f.samples) == 1}
         res = {
-            "backend": a.backend, "replicate": max(1, a.replicate), "gpus": gpus, "sample_interval_ms": a.interval_ms, "scrape_hz": a.scrape_hz,
+            "backend": a.backend, "health": bool(a.health), "replicate": max(1, a.replicate), "gpus": gpus, "sample_interval_ms": a.interval_ms, "scrape_hz": a.scrape_hz,
             "seconds": round(wall, 1), "scrapes": len(lat),
             "scrape_ms": {"p50": round(statistics.median(lat), 3), "p90": round(pct(lat, 0.9), 3),
                           "p99": round(pct(lat, 0.99), 3), "max": round(max(lat), 3)},
