@@ -10,8 +10,9 @@ A step, on every rank (= one MI355X), runs the whole diag suite once:
   rccl     all-reduce / all-gather / all-to-all of 1 GiB over xGMI   (N > 1)
   scrape   rank 0 fetches /metrics from the gpumon-exporter child process
 The exporter child is the production binary with the amdsmi backend, watching all
-of the node's GPUs at 1 s with profiling + AMD extra families; its CPU time is
-read from /proc over the timed window.
+of the node's GPUs at 1 s with profiling + AMD extra families, the health check and the
+policy registration (gpumon_health_*, gpumon_policy_violations_total); its CPU time is
+read from /proc over a window of at least ten seconds.
 
 `value` is the aggregate bf16 GEMM rate of the job (sum over ranks); the other
 headline numbers (HBM TB/s, MX-fp8 TFLOPS, RCCL bus bandwidth, scrape p50,
@@ -64,8 +65,8 @@ class ExporterChild:
         if backend == "fake":
             env.setdefault("GPUMON_BACKEND_SPEC", "gpus=8,seed=1")
         self.proc = subprocess.Popen(
-            [binary("gpumon-exporter"), "-e", "-p", "-o", "", "-d", str(int(interval_ms)), "--extras", "--self-metrics", "--listen",
-             "127.0.0.1:0", *extra_args], stderr=subprocess.PIPE, text=True, env=env)
+            [binary("gpumon-exporter"), "-e", "-p", "-o", "", "-d", str(int(interval_ms)), "--extras", "--self-metrics", "--health",
+             "--listen", "127.0.0.1:0", *extra_args], stderr=subprocess.PIPE, text=True, env=env)
         self.port = None
         self.log = []
         deadline = time.time() + 60

@@ -2,7 +2,7 @@
 """Scrape-latency and exporter-CPU benchmark: the operating point the exporter is
 built for (8 GPUs, 1 s resolution, under 1 % of a host core, p50 scrape under 50 ms).
 
-Starts `gpumon-exporter -e -p --extras --self-metrics --listen 127.0.0.1:0` as a
+Starts `gpumon-exporter -e -p --extras --self-metrics --health --listen 127.0.0.1:0` as a
 child (fake backend with N scripted GPUs, or amdsmi on a GPU box), scrapes
 /metrics over a fresh HTTP connection at --scrape-hz for --seconds, and reports
 latency percentiles, the child's on-CPU time as a share of wall time (all its
@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--scrape-hz", type=float, default=1.0)
     ap.add_argument("--replicate", type=int, default=0, help="present every device of the backend N times")
     ap.add_argument("--interval-ms", type=int, default=1000, help="exporter sampling interval (its floor is 100)")
-    ap.add_argument("--health", action="store_true", help="the exporter also runs the health check and counts policy violations")
+    ap.add_argument("--health", action="store_true", help="kept for old command lines: the exporter child always runs the health check")
     ap.add_argument("--out")
     a = ap.parse_args()
 
@@ -55,7 +55,7 @@ def main():
         spec.append(f"replicate={a.replicate}")
     if spec:
         os.environ["GPUMON_BACKEND_SPEC"] = ",".join(spec)
-    ex = ExporterChild(a.backend, interval_ms=a.interval_ms, extra_args=["--health"] if a.health else [])
+    ex = ExporterChild(a.backend, interval_ms=a.interval_ms, extra_args=[])  # the child always runs with --health
     try:
         time.sleep(1.5)  # first sweep done, static attributes cached
         ex.scrape()
@@ -75,7 +75,7 @@ def main():
         gpus = len({l.get("gpu") for l, _ in fams["dcgm_sm_clock"].samples})
         self_metrics = {n: f.samples[0][1] for n, f in fams.items() if n.startswith("gpumon_") and len(f.samples) == 1}
         res = {
-            "backend": a.backend, "health": bool(a.health), "replicate": max(1, a.replicate), "gpus": gpus, "sample_interval_ms": a.interval_ms, "scrape_hz": a.scrape_hz,
+            "backend": a.backend, "health": True, "replicate": max(1, a.replicate), "gpus": gpus, "sample_interval_ms": a.interval_ms, "scrape_hz": a.scrape_hz,
             "seconds": round(wall, 1), "scrapes": len(lat),
             "scrape_ms": {"p50": round(statistics.median(lat), 3), "p90": round(pct(lat, 0.9), 3),
                           "p99": round(pct(lat, 0.99), 3), "max": round(max(lat), 3)},
