@@ -137,6 +137,7 @@ int main(int argc, char** argv) {
     cfg.rest_api = 1;
     cfg.self_metrics = 1;
     cfg.amd_extras = 1;
+    cfg.health = 1;  // the daemon's /metrics carries the health verdicts and policy violation counts too
     if (gm_exporter_create(&cfg, &ex) == GM_ST_OK && gm_exporter_start(ex) == GM_ST_OK) have_http = true;
     else fprintf(stderr, "warning: cannot serve HTTP on %s\n", http.c_str());
   }
