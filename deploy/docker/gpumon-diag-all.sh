@@ -1,0 +1,38 @@
+#!/bin/bash
+# Runs the diagnostics on every GPU the container (or the host) sees, one GPU after the other, and leaves one report
+# per GPU in $GPUMON_DIAG_DIR for `gpumon-exporter --diag-results DIR`.  With more than one GPU it ends with the
+# xGMI link test and a short RCCL sweep over all of them.  Exit status: 0 when every test passed, 1 when a test
+# failed, 2 when the diagnostics could not run.
+#   GPUMON_DIAG_LEVEL   1 (seconds), 2 (about a minute per GPU, default), 3 (soak)
+#   GPUMON_DIAG_DIR     report directory (default /var/lib/gpumon/diag)
+#   GPUMON_DIAG_SUBMIT  address of a host engine that also gets the verdicts (e.g. 127.0.0.1:5555); empty = none
+set -u
+LEVEL=${GPUMON_DIAG_LEVEL:-2}
+DIR=${GPUMON_DIAG_DIR:-/var/lib/gpumon/diag}
+SUBMIT=${GPUMON_DIAG_SUBMIT:-}
+DIAG=${GPUMON_DIAG_BIN:-gpumon-diag}
+mkdir -p "$DIR" || exit 2
+info=$("$DIAG" info) || { echo "gpumon-diag-all: no GPU to test" >&2; exit 2; }
+n=$(printf '%s\n' "$info" | grep -c '^GPU ')
+[ "$n" -gt 0 ] || { echo "gpumon-diag-all: no GPU to test" >&2; exit 2; }
+extra=()
+[ -n "$SUBMIT" ] && extra=(--submit "$SUBMIT")
+worst=0
+note() {  # keep the worst status: 2 (could not run) over 1 (failed) over 0
+  [ "$1" -gt "$worst" ] && worst=$1
+  return 0
+}
+for ((g = 0; g < n; g++)); do
+  echo "=== GPU $g: level $LEVEL"
+  "$DIAG" run -r "$LEVEL" -g "$g" --publish "$DIR/gpu$g.json" "${extra[@]}"
+  note $?
+done
+if [ "$n" -gt 1 ]; then
+  echo "=== xGMI links"
+  "$DIAG" links --publish "$DIR/links.json" "${extra[@]}"
+  note $?
+  echo "=== RCCL"
+  "$DIAG" rccl --max-bytes 256M --factor 16 --publish "$DIR/rccl.json" "${extra[@]}"
+  note $?
+fi
+exit "$worst"

@@ -177,3 +177,49 @@ def test_one_listener_per_port_in_every_pod(tmp_path):
             assert r.returncode == 0 and "gpumon_health_overall" in out.read_text(), (path, r.stderr)
             checked += 1
     assert checked == 4
+
+
+def test_all_gpu_diagnostics_wrapper(tmp_path):
+    """deploy/docker/gpumon-diag-all.sh with a stand-in for gpumon-diag: one run per GPU, link test and RCCL sweep only
+    with more than one GPU, reports in the directory, the worst exit status wins, flags are ones gpumon-diag knows."""
+    script = os.path.join(DEPLOY, "docker", "gpumon-diag-all.sh")
+    stub = tmp_path / "gpumon-diag"
+    stub.write_text("""#!/bin/bash
+echo "$@" >> "$STUB_LOG"
+if [ "$1" = info ]; then
+  for ((i = 0; i < STUB_GPUS; i++)); do echo "GPU $i: AMD Instinct MI355X (gfx950) 0000:0$i:00.0  CUs 256"; done
+  [ "$STUB_GPUS" -gt 0 ]; exit $?
+fi
+prev=""
+for a in "$@"; do [ "$prev" = --publish ] && echo '{}' > "$a"; prev=$a; done
+[ "$1" = run ] && [ "$4" = "-g" ] && [ "$5" = "${STUB_FAIL_GPU:-none}" ] && exit 1
+exit 0
+""")
+    stub.chmod(0o755)
+
+    def run(gpus, **env):
+        log, out = tmp_path / f"log{gpus}{len(env)}", tmp_path / f"out{gpus}{len(env)}"
+        e = dict(os.environ, GPUMON_DIAG_BIN=str(stub), GPUMON_DIAG_DIR=str(out), STUB_LOG=str(log), STUB_GPUS=str(gpus), **env)
+        r = subprocess.run(["bash", script], env=e, capture_output=True, text=True, timeout=30)
+        calls = log.read_text().splitlines() if log.exists() else []
+        return r.returncode, calls, sorted(p.name for p in out.iterdir()) if out.exists() else []
+
+    rc, calls, files = run(1)
+    assert rc == 0 and calls == ["info", f"run -r 2 -g 0 --publish {tmp_path}/out10/gpu0.json"] and files == ["gpu0.json"]
+    rc, calls, files = run(3, GPUMON_DIAG_LEVEL="1", GPUMON_DIAG_SUBMIT="127.0.0.1:5555", STUB_FAIL_GPU="1")
+    assert rc == 1 and len(calls) == 1 + 3 + 2 and files == ["gpu0.json", "gpu1.json", "gpu2.json", "links.json", "rccl.json"]
+    assert calls[2].startswith("run -r 1 -g 1 ") and calls[2].endswith("--submit 127.0.0.1:5555")
+    assert calls[4].startswith("links --publish") and calls[5].startswith("rccl --max-bytes 256M --factor 16 --publish")
+    assert run(0)[0] == 2
+    # every flag the script passes is one the real binary parses
+    src = open(os.path.join(ROOT, "cmd", "gpumon-diag.cc")).read()
+    for flag in ("-r", "-g", "--publish", "--submit", "--max-bytes", "--factor"):
+        assert f'"{flag}"' in src, flag
+    ep = _entrypoint("gpumon-diag.Dockerfile")
+    assert ep == ["gpumon-diag-all"] and "gpumon-diag-all.sh /usr/local/bin/gpumon-diag-all" in open(
+        os.path.join(DEPLOY, "docker", "gpumon-diag.Dockerfile")).read()
+    cron = yaml.safe_load(open(os.path.join(DEPLOY, "k8s", "diag", "gpumon-diag-cronjob.yaml")))
+    pod = cron["spec"]["jobTemplate"]["spec"]["template"]["spec"]
+    assert cron["kind"] == "CronJob" and pod["restartPolicy"] == "Never" and pod["nodeSelector"] == {"hardware-type": "AMDGPU"}
+    assert pod["containers"][0]["resources"]["limits"] == {"amd.com/gpu": 8}
+    assert pod["volumes"][0]["hostPath"]["path"] == "/var/lib/gpumon/diag"
