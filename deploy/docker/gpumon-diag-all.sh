@@ -2,7 +2,7 @@
 # Runs the diagnostics on every GPU the container (or the host) sees, one GPU after the other, and leaves one report
 # per GPU in $GPUMON_DIAG_DIR for `gpumon-exporter --diag-results DIR`.  With more than one GPU it ends with the
 # xGMI link test and a short RCCL sweep over all of them.  Exit status: 0 when every test passed, 1 when a test
-# failed, 2 when the diagnostics could not run.
+# failed, 2 when the diagnostics could not run or a step died (nothing is started after a step that was killed).
 #   GPUMON_DIAG_LEVEL   1 (seconds), 2 (about a minute per GPU, default), 3 (soak)
 #   GPUMON_DIAG_DIR     report directory (default /var/lib/gpumon/diag)
 #   GPUMON_DIAG_SUBMIT  address of a host engine that also gets the verdicts (e.g. 127.0.0.1:5555); empty = none
@@ -19,6 +19,12 @@ extra=()
 [ -n "$SUBMIT" ] && extra=(--submit "$SUBMIT")
 worst=0
 note() {  # keep the worst status: 2 (could not run) over 1 (failed) over 0
+  if [ "$1" -ge 124 ]; then
+    # killed by a signal or a time limit (abort, segmentation fault, GPU fault): nothing more is started on the
+    # GPUs of this node, the operator reads what the run left
+    echo "gpumon-diag-all: the last step ended with status $1; stopping" >&2
+    exit 2
+  fi
   [ "$1" -gt "$worst" ] && worst=$1
   return 0
 }

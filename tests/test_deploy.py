@@ -193,6 +193,7 @@ fi
 prev=""
 for a in "$@"; do [ "$prev" = --publish ] && echo '{}' > "$a"; prev=$a; done
 [ "$1" = run ] && [ "$4" = "-g" ] && [ "$5" = "${STUB_FAIL_GPU:-none}" ] && exit 1
+[ "$1" = run ] && [ "$4" = "-g" ] && [ "$5" = "${STUB_CRASH_GPU:-none}" ] && kill -SEGV $$
 exit 0
 """)
     stub.chmod(0o755)
@@ -211,6 +212,8 @@ exit 0
     assert calls[2].startswith("run -r 1 -g 1 ") and calls[2].endswith("--submit 127.0.0.1:5555")
     assert calls[4].startswith("links --publish") and calls[5].startswith("rccl --max-bytes 256M --factor 16 --publish")
     assert run(0)[0] == 2
+    rc, calls, files = run(4, STUB_CRASH_GPU="1", X="1", Y="2")  # GPU 1's run dies: GPUs 2 and 3, links and RCCL are not started
+    assert rc == 2 and [c.split()[0:5] for c in calls[1:]] == [["run", "-r", "2", "-g", "0"], ["run", "-r", "2", "-g", "1"]]
     # every flag the script passes is one the real binary parses
     src = open(os.path.join(ROOT, "cmd", "gpumon-diag.cc")).read()
     for flag in ("-r", "-g", "--publish", "--submit", "--max-bytes", "--factor"):
