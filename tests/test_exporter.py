@@ -474,7 +474,15 @@ def test_health_families_follow_the_engine_health_check(engine2):
         assert sample(f, "gpumon_health_overall", gpu="0") == 20 and sample(f, "gpumon_health_overall", gpu="1") == 10
         assert sample(f, "gpumon_health_incidents_total", gpu="1", system="thermal", level="warning") == 1
         assert sample(f, "gpumon_health_incidents_total", gpu="0", system="xgmi", level="failure") >= 1
-        # the same conditions through the policy engine: the link that went down is an xGMI violation of GPU 0
+        # the same conditions through the policy engine: the link that went down is an xGMI violation of GPU 0.
+        # Violations are delivered on the engine's notifier thread, so the counts may trail the sweep by a moment.
+        deadline = time.time() + 5
+        while True:
+            f = parse(ex.render())
+            if (sample(f, "gpumon_policy_violations_total", gpu="0", condition="xgmi") >= 1 and
+                    sample(f, "gpumon_policy_violations_total", gpu="1", condition="thermal") >= 1) or time.time() > deadline:
+                break
+            time.sleep(0.05)
         assert sample(f, "gpumon_policy_violations_total", gpu="0", condition="xgmi") >= 1
         assert sample(f, "gpumon_policy_violations_total", gpu="1", condition="thermal") == 1  # 104 C against the 100 C default
         assert sample(f, "gpumon_policy_violations_total", gpu="1", condition="power") == 0
