@@ -382,7 +382,13 @@ void Exporter::render(std::string* out) {
           if (!emit_sample(fam, m, g) && g == 0 && out->size() == after_header) out->resize(mark);
         }
   }
-  if (cfg_.health && health_valid_) render_health(base, podl, out);
+  if (cfg_.health) {
+    // A check that could not run (the engine went away) must not look like a clean bill of health: the verdict
+    // families are left out and this gauge says why.
+    *out += strprintf("# HELP gpumon_health_check_up 1 if the last health check ran, 0 if the engine refused or could not be reached.\n"
+                      "# TYPE gpumon_health_check_up gauge\ngpumon_health_check_up %d\n", health_valid_ ? 1 : 0);
+    if (health_valid_) render_health(base, podl, out);
+  }
   if (cfg_.self_metrics) render_self(out);
   if (!cfg_.diag_results_path.empty()) render_diag_results(cfg_.diag_results_path, out, engine_);
   last_render_us_ = monotonic_us() - t0;

@@ -5,6 +5,7 @@ Covers the three run modes of the reference's Init (bindings/go/dcgm/admin.go:26
 TCP) and start-hostengine (spawn a private daemon as a child)."""
 import json
 import os
+import re
 import signal
 import socket
 import subprocess
@@ -239,3 +240,48 @@ def test_cli_policy_and_events_embedded():
     r = subprocess.run([bin_path("gpumon"), "pidinfo", "-pid", "1", "--wait", "100"], env=env, capture_output=True,
                        text=True, timeout=20)
     assert r.returncode == 1 and "no GPU activity" in r.stderr
+
+
+def test_exporter_says_when_the_health_check_cannot_run(tmp_path):
+    """An exporter connected to a host engine that goes away: the verdict families disappear (no stale "all healthy")
+    and gpumon_health_check_up turns 0, which is what the GpuHealthCheckDown alert reads."""
+    import urllib.request
+    sock = str(tmp_path / "he.sock")
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=2")
+    he = subprocess.Popen([bin_path("gpumon-hostengine"), "--domain-socket", sock], env=env, stderr=subprocess.PIPE, text=True)
+    ex = None
+    try:
+        assert "listening" in he.stderr.readline()
+        ex = subprocess.Popen([bin_path("gpumon-exporter"), "-connect", sock, "-socket", "--health", "-o", "", "-d", "200", "--listen",
+                               "127.0.0.1:0"], stderr=subprocess.PIPE, text=True)
+        port = None
+        for _ in range(50):
+            m = re.search(r"Serving /metrics on port (\d+)", ex.stderr.readline())
+            if m:
+                port = int(m.group(1))
+                break
+        assert port
+
+        def body():
+            return urllib.request.urlopen(f"http://127.0.0.1:{port}/metrics", timeout=5).read().decode()
+
+        def wait_for(pred):
+            deadline = time.time() + 10
+            while time.time() < deadline:
+                b = body()
+                if pred(b):
+                    return b
+                time.sleep(0.1)
+            return body()
+
+        b = wait_for(lambda t: "gpumon_health_check_up 1" in t)
+        assert "gpumon_health_check_up 1" in b and b.count("\ngpumon_health_status{") == 16
+        he.terminate()
+        he.wait(timeout=10)
+        b = wait_for(lambda t: "gpumon_health_check_up 0" in t)
+        assert "gpumon_health_check_up 0" in b and "gpumon_health_status{" not in b
+    finally:
+        for p in (ex, he):
+            if p and p.poll() is None:
+                p.kill()
+                p.wait()

@@ -462,6 +462,7 @@ def test_health_families_follow_the_engine_health_check(engine2):
         ex.sweep()
         f = parse(ex.render())
         assert len(f["gpumon_health_status"].samples) == 2 * 8 and f["gpumon_health_incidents_total"].type == "counter"
+        assert f["gpumon_health_check_up"].samples == [({}, 1.0)]
         assert all(v == 0 for _l, v in f["gpumon_health_status"].samples + f["gpumon_health_overall"].samples)
         E.fake_ctl("set gpu=1 field=150 value=104")  # hot: thermal warning
         E.fake_ctl("link_down gpu=0 link=0")          # xGMI link down: failure
