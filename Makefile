@@ -47,7 +47,7 @@ $(BUILD)/bin/%: cmd/%.cc cmd/cli_common.h include/gpumon.h $(BUILD)/libgpumon.so
 # ---- active diagnostics: hand-written CDNA4 kernels --------------------------
 $(BUILD)/obj/%.o: %.hip
 	@mkdir -p $(dir $@)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -MMD -MP -c $< -o $@
 
 diag: $(BUILD)/libgpumon_diag.so $(BUILD)/bin/gpumon-diag
 $(BUILD)/libgpumon_diag.so: $(DIAG_OBJ)
@@ -91,4 +91,4 @@ asan:
 clean:
 	rm -rf build build-tsan build-asan
 
--include $(CORE_OBJ:.o=.d)
+-include $(CORE_OBJ:.o=.d) $(DIAG_OBJ:.o=.d)

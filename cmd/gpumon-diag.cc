@@ -3,16 +3,20 @@
 // bindings/go/dcgm/health.go:55-119).
 //
 //   gpumon-diag info                       HIP-side device facts
-//   gpumon-diag hbm    [-g GPU] [--bytes N] [--iters N] [--kernel NAME|all] [--min-tbps X]
-//   gpumon-diag memtest[-g GPU] [--bytes N | --fraction F] [--patterns a,b] [--passes N]
-//   gpumon-diag mfma   [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]
-//   gpumon-diag gemm   [-g GPU] [--dtype bf16|fp8|mxfp8] [--m M --n N --k K] [--seconds S] [--no-telemetry] [--mfma-counters]
-//   gpumon-diag rccl   [--gpus 0,1,..] [--ops a,b] [--min-bytes N] [--max-bytes N] [--scaling]
-//   gpumon-diag links  [--gpus 0,1,..] [--bytes N] [--modes uni,bidi,all] [--floor-gbps X]   (alias: p2p)
-//   gpumon-diag run -r 1|2|3 [-g GPU]      graded suites: quick / medium / long
+//   gpumon-diag hbm    [-g GPU | --gpus LIST|all] [--bytes N] [--iters N] [--kernel NAME|all] [--min-tbps X]
+//   gpumon-diag memtest[-g GPU | --gpus LIST|all] [--bytes N | --fraction F] [--patterns a,b] [--passes N]
+//   gpumon-diag mfma   [-g GPU | --gpus LIST|all] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]
+//   gpumon-diag gemm   [-g GPU | --gpus LIST|all] [--dtype bf16|fp8|mxfp8] [--m M --n N --k K] [--seconds S] [--check-every N]
+//   gpumon-diag rccl   [--gpus 0,1,..] [--ops a,b] [--min-bytes N] [--max-bytes N] [--scaling] [--min-busbw X]
+//   gpumon-diag links  [--gpus 0,1,..] [--bytes N] [--modes uni,bidi,all] [--direction push|pull|both]   (alias: p2p)
+//   gpumon-diag run -r 1|2|3 [-g GPU | --gpus LIST|all] [--no-fabric]   graded suites: quick / medium / long
+// Grading: every throughput is held against what a healthy GPU of this model delivers (cmd/diag_expect.h):
+// PASS, WARN below 90 %, FAIL below 75 %; --expect key=value,.. replaces entries, --expect-scale F scales them,
+// --no-expect grades correctness only.  With several GPUs every GPU runs the test at the same time (one host thread
+// and stream set per GPU) and is also held against the median of the others.
 // Every command takes --json and --publish FILE (leave the JSON report where
 // `gpumon-exporter --diag-results` picks it up and exports it as gpumon_diag_* metrics).
-// Exit status: 0 pass, 1 a test failed, 2 usage / setup error.
+// Exit status: 0 pass (warnings included), 1 a test failed, 2 usage / setup error.
 #include <unistd.h>
 #include <signal.h>
 #include <spawn.h>
@@ -26,12 +30,14 @@
 #include <cstdarg>
 #include <ctime>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
 
 #include "../diag/gpumon_diag.h"
 #include "cli_common.h"
+#include "diag_expect.h"
 
 namespace {
 
@@ -59,7 +65,8 @@ struct Args {
 const char* kFlagsWithValue[] = {"-g", "--bytes", "--iters", "--kernel", "--min-tbps", "--fraction", "--patterns", "--passes",
                                  "--dtype", "--seconds", "--m", "--n", "--k", "--gpus", "--ops", "--min-bytes",
                                  "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor", "--publish", "--modes", "--floor-gbps",
-                                 "--warn-ratio", "--fail-ratio", "--workgroups", "--submit", "--min-busbw"};
+                                 "--warn-ratio", "--fail-ratio", "--workgroups", "--submit", "--min-busbw", "--expect", "--expect-scale",
+                                 "--check-every", "--direction", "--link-gbps", "--outlier-warn", "--outlier-fail", "--arch", "--name", "--check"};
 
 bool parse(const std::vector<std::string>& in, Args* a) {
   for (size_t i = 0; i < in.size(); i++) {
@@ -94,35 +101,56 @@ std::vector<std::string> csv(const std::string& s) {
   return out;
 }
 
-// Collected output: a text report and a JSON document built side by side.
+// Collected output: a text report and a JSON document built side by side.  A report is about one GPU, or about
+// the node (fabric tests, several GPUs at once): then it holds one sub-report per GPU.
 struct Report {
   bool json = false;
-  bool failed = false;
-  std::string js;  // comma-joined members of the top-level object
+  bool failed = false, warned = false;
+  bool buffered = false;  // text goes to `out` instead of stdout (a GPU's thread of a concurrent run)
+  std::string out;
+  std::string js;       // comma-joined members of the top-level object
+  int gpu = -1;         // HIP device this report is about; -1 = the node
+  std::string pci_bdf;  // of that device: what the engine and the exporter find the card by
+  std::map<std::string, double> metrics;  // measured rates by expectation key, for the comparison between GPUs
+  std::vector<Report> subs;               // per-GPU reports of a node report
+
   void text(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
     if (json) return;
+    char b[1024];
     va_list ap;
     va_start(ap, fmt);
-    vprintf(fmt, ap);
+    vsnprintf(b, sizeof b, fmt, ap);
     va_end(ap);
+    if (buffered) {
+      out += b;
+      return;
+    }
+    fputs(b, stdout);
     fflush(stdout);
   }
   void member(const std::string& key, const std::string& value) {
     if (!js.empty()) js += ",";
     js += "\"" + key + "\":" + value;
   }
+  void complain(int health, const std::string& msg) {
+    if (health >= GM_HEALTH_FAIL) failed = true;
+    else if (health >= GM_HEALTH_WARN) warned = true;
+    else return;
+    const std::string line = std::string(health >= GM_HEALTH_FAIL ? "FAIL: " : "WARN: ") + msg + "\n";
+    if (buffered) out += json ? "" : "  " + line;
+    else fputs(line.c_str(), stderr);
+  }
   void fail(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
-    failed = true;
+    char b[512];
     va_list ap;
     va_start(ap, fmt);
-    fprintf(stderr, "FAIL: ");
-    vfprintf(stderr, fmt, ap);
-    fprintf(stderr, "\n");
+    vsnprintf(b, sizeof b, fmt, ap);
     va_end(ap);
+    complain(GM_HEALTH_FAIL, b);
   }
-  // Per-test verdicts, the part of the report the host engine understands (gm_diag_result_t): a failure is kept
-  // as the test's verdict and fails the run; a pass is recorded only where the test has no failure yet, so that a
-  // later clean run replaces an old failure in the engine.
+  // Per-test verdicts, the part of the report the host engine understands (gm_diag_result_t).  One verdict per
+  // (test, GPU): the worst health a test reached is its verdict, and a pass is recorded only where the test has
+  // nothing worse, so that a later clean run replaces an old failure in the engine.
   struct Verdict {
     std::string test;
     uint32_t system;  // GM_HEALTH_WATCH_* bit
@@ -130,19 +158,22 @@ struct Report {
     double value;
     std::string message;
     int gpu = -1;  // HIP device the verdict is about; -1 = the report's GPU
+    std::string pci_bdf;
   };
   std::vector<Verdict> verdicts;
-  // A verdict about one GPU of a multi-GPU test (the link test): one per (test, gpu), the worst health wins.
-  void verdict_for_gpu(int gpu, const std::string& test, uint32_t system, int health, double value, const std::string& message) {
-    if (health == GM_HEALTH_FAIL) fail("GPU %d: %s", gpu, message.c_str());
+  void verdict(const std::string& test, uint32_t system, int health, double value, const std::string& message, int for_gpu = -1) {
+    if (health > GM_HEALTH_PASS) complain(health, for_gpu >= 0 ? "GPU " + std::to_string(for_gpu) + ": " + message : message);
     for (auto& v : verdicts)
-      if (v.test == test && v.gpu == gpu) {
+      if (v.test == test && v.gpu == for_gpu) {
         if (health > v.health) v.health = health, v.value = value, v.message = message;
         return;
       }
     Verdict v{test, system, health, value, message};
-    v.gpu = gpu;
+    v.gpu = for_gpu;
     verdicts.push_back(v);
+  }
+  void verdict_for_gpu(int g, const std::string& test, uint32_t system, int health, double value, const std::string& message) {
+    verdict(test, system, health, value, message, g);
   }
   void verdict_fail(const std::string& test, uint32_t system, double value, const char* fmt, ...) __attribute__((format(printf, 5, 6))) {
     char buf[192];
@@ -150,41 +181,77 @@ struct Report {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    fail("%s", buf);
-    for (auto& v : verdicts)
-      if (v.test == test && v.health == GM_HEALTH_FAIL) return;  // the first failure of a test is its verdict
-    for (auto it = verdicts.begin(); it != verdicts.end();)
-      it = it->test == test ? verdicts.erase(it) : it + 1;
-    verdicts.push_back({test, system, GM_HEALTH_FAIL, value, buf});
+    verdict(test, system, GM_HEALTH_FAIL, value, buf);
   }
   void verdict_pass(const std::string& test, uint32_t system, double value, const std::string& message) {
-    for (auto& v : verdicts)
-      if (v.test == test) return;
-    verdicts.push_back({test, system, GM_HEALTH_PASS, value, message});
+    verdict(test, system, GM_HEALTH_PASS, value, message);
   }
-  // The whole report as one JSON object; `gpu` and `timestamp` let the exporter label and age it.
-  std::string document(int gpu) const {
+  // A throughput against its expectation: records WARN / FAIL, returns the health.
+  int grade(const std::string& test, uint32_t system, const std::string& what, double value, double want, const diag_expect::Expect& e,
+            const char* unit) {
+    const int h = diag_expect::grade_rate(value, want, e);
+    if (h) {
+      char b[192];
+      snprintf(b, sizeof b, "%s %.4g %s is %.0f %% of the %.4g %s expected", what.c_str(), value, unit, 100 * value / want, want, unit);
+      verdict(test, system, h, value, b);
+    }
+    return h;
+  }
+
+  static std::string escape(const std::string& in) {
+    std::string o;
+    for (char c : in) {
+      if (c == '"' || c == '\\') o += '\\';
+      o += (unsigned char)c < 0x20 ? ' ' : c;
+    }
+    return o;
+  }
+  std::string verdicts_json(const std::function<std::string(int)>& bdf_of) const {
     std::string vj = "[";
     for (size_t i = 0; i < verdicts.size(); i++) {
       const Verdict& v = verdicts[i];
       char num[64];
       if (std::isfinite(v.value)) snprintf(num, sizeof num, "%.6g", v.value); else snprintf(num, sizeof num, "null");
-      std::string msg;
-      for (char c : v.message) {
-        if (c == '"' || c == '\\') msg += '\\';
-        msg += (unsigned char)c < 0x20 ? ' ' : c;
-      }
-      vj += std::string(i ? "," : "") + "{\"test\":\"" + v.test + "\"," + (v.gpu >= 0 ? "\"gpu\":" + std::to_string(v.gpu) + "," : "") +
-            "\"system\":" + std::to_string(v.system) + ",\"health\":" +
-            std::to_string(v.health) + ",\"value\":" + num + ",\"message\":\"" + msg + "\"}";
+      const int g = v.gpu >= 0 ? v.gpu : gpu;
+      const std::string bdf = !v.pci_bdf.empty() ? v.pci_bdf : g >= 0 ? bdf_of(g) : "";
+      vj += std::string(i ? "," : "") + "{\"test\":\"" + v.test + "\"," + (g >= 0 ? "\"gpu\":" + std::to_string(g) + "," : "") +
+            (bdf.empty() ? "" : "\"pci_bdf\":\"" + escape(bdf) + "\",") + "\"system\":" + std::to_string(v.system) + ",\"health\":" +
+            std::to_string(v.health) + ",\"value\":" + num + ",\"message\":\"" + escape(v.message) + "\"}";
     }
-    return "{\"gpu\":" + std::to_string(gpu) + ",\"timestamp\":" + std::to_string((long long)time(nullptr)) +
-           (js.empty() ? "" : "," + js) + ",\"verdicts\":" + vj + "],\"result\":\"" + (failed ? "fail" : "pass") + "\"}";
+    return vj + "]";
   }
-  int finish(int gpu, const std::string& publish_path) {
-    const std::string doc = document(gpu);
+  const char* result() const { return failed ? "fail" : warned ? "warn" : "pass"; }
+  // The whole report as one JSON object; `gpu`, `pci_bdf` and `timestamp` let the exporter label and age it.  A node
+  // report carries its per-GPU reports under "gpus" and every verdict (its own and theirs) under "verdicts".
+  std::string document(const std::function<std::string(int)>& bdf_of) const {
+    std::string d = "{\"scope\":\"" + std::string(gpu >= 0 ? "gpu" : "node") + "\"";
+    if (gpu >= 0) d += ",\"gpu\":" + std::to_string(gpu) + ",\"pci_bdf\":\"" + escape(pci_bdf.empty() ? bdf_of(gpu) : pci_bdf) + "\"";
+    d += ",\"timestamp\":" + std::to_string((long long)time(nullptr));
+    if (!js.empty()) d += "," + js;
+    if (!subs.empty()) {
+      d += ",\"gpus\":[";
+      for (size_t i = 0; i < subs.size(); i++) d += (i ? "," : "") + subs[i].document(bdf_of);
+      d += "]";
+    }
+    Report all = all_verdicts();
+    return d + ",\"verdicts\":" + all.verdicts_json(bdf_of) + ",\"result\":\"" + result() + "\"}";
+  }
+  // This report's verdicts and, for a node report, those of its per-GPU reports with the GPU filled in.
+  Report all_verdicts() const {
+    Report all;
+    all.gpu = gpu;
+    all.verdicts = verdicts;
+    for (auto& s : subs)
+      for (auto v : s.verdicts) {
+        if (v.gpu < 0) v.gpu = s.gpu;
+        all.verdicts.push_back(v);
+      }
+    return all;
+  }
+  int finish(const std::string& publish_path, const std::function<std::string(int)>& bdf_of) {
+    const std::string doc = document(bdf_of);
     if (json) printf("%s\n", doc.c_str());
-    else printf("\nResult: %s\n", failed ? "FAIL" : "PASS");
+    else printf("\nResult: %s\n", failed ? "FAIL" : warned ? "WARN" : "PASS");
     if (!publish_path.empty()) {
       // temp + rename: the exporter never reads a half-written report
       const std::string tmp = publish_path + ".swp";
@@ -249,6 +316,60 @@ int dtype_of(const std::string& s) {
   return -1;
 }
 
+// PCI address of a HIP device ("" when it cannot be read): the identity that the engine, whose numbering follows
+// the PCI bus, and the compute runtime, whose numbering may not, share.
+std::string bdf_of_hip(int gpu) {
+  static std::mutex mu;
+  static std::map<int, std::string> cache;
+  std::lock_guard<std::mutex> l(mu);
+  auto it = cache.find(gpu);
+  if (it != cache.end()) return it->second;
+  gmd_device_info_t d;
+  std::string b = gmd_device_info(gpu, &d) == GMD_OK ? d.pci_bdf : "";
+  cache[gpu] = b;
+  return b;
+}
+
+// The expectation table entry of a GPU with the command line's replacements applied.
+bool expect_for(const Args& a, int gpu, diag_expect::Expect* e) {
+  gmd_device_info_t d;
+  memset(&d, 0, sizeof d);
+  if (!a.has("--no-expect") && gmd_device_info(gpu, &d) == GMD_OK) *e = diag_expect::lookup(d.gcn_arch, d.name);
+  std::string bad;
+  if (a.has("--expect") && !a.has("--no-expect") && !diag_expect::apply_overrides(a.str("--expect"), e, &bad)) {
+    fprintf(stderr, "--expect: cannot read '%s' (key=value, value >= 0)\n", bad.c_str());
+    return false;
+  }
+  e->scale = a.num("--expect-scale", 1.0);
+  if (!(e->scale > 0)) e->scale = 1.0;
+  return true;
+}
+
+// -g N, --gpus a,b,c or --gpus all.  Empty = no GPU visible or a bad list.
+std::vector<int> target_gpus(const Args& a) {
+  std::vector<int> ids;
+  const int visible = gmd_device_count();
+  if (a.has("--gpus")) {
+    if (a.str("--gpus") == "all")
+      for (int i = 0; i < visible; i++) ids.push_back(i);
+    else
+      for (auto& t : csv(a.str("--gpus"))) {
+        const int g = atoi(t.c_str());
+        // GPUMON_DIAG_ALLOW_REPEAT=1 lets a GPU appear twice: two host threads on one card, which is how the
+        // concurrent path is exercised on a machine with a single GPU
+        const bool repeat_ok = getenv("GPUMON_DIAG_ALLOW_REPEAT") != nullptr;
+        if (g < 0 || g >= visible || (!repeat_ok && std::find(ids.begin(), ids.end(), g) != ids.end())) {
+          fprintf(stderr, "--gpus: bad or repeated GPU %s (%d visible)\n", t.c_str(), visible);
+          return {};
+        }
+        ids.push_back(g);
+      }
+  } else {
+    ids.push_back((int)a.num("-g", 0));
+  }
+  return ids;
+}
+
 // ------------------------------------------------------------------ commands --
 int cmd_info(const Args& a, Report& r) {
   int n = gmd_device_count();
@@ -271,14 +392,15 @@ int cmd_info(const Args& a, Report& r) {
   return 0;
 }
 
-int cmd_hbm(const Args& a, Report& r) {
-  const int gpu = (int)a.num("-g", 0);
+int cmd_hbm(const Args& a, Report& r, int gpu) {
   const uint64_t bytes = a.size("--bytes", 4ull << 30);
   const int iters = (int)a.num("--iters", 10);
   const std::string which = a.str("--kernel", "all");
   const double floor_tbps = a.num("--min-tbps", 0);
-  r.text("HBM stream on GPU %d, %.1f GiB per buffer, %d iterations\n  %-8s %10s %10s %8s\n", gpu, bytes / 1073741824.0, iters,
-         "kernel", "best TB/s", "median", "check");
+  diag_expect::Expect e;
+  if (!expect_for(a, gpu, &e)) return 2;
+  r.text("HBM stream on GPU %d, %.1f GiB per buffer, %d iterations\n  %-8s %10s %10s %10s %8s\n", gpu, bytes / 1073741824.0, iters,
+         "kernel", "best TB/s", "median", "expected", "check");
   std::string obj = "{";
   bool any = false;
   double worst = 1e30;
@@ -286,20 +408,28 @@ int cmd_hbm(const Args& a, Report& r) {
     if (which != "all" && which != kStreamNames[k]) continue;
     gmd_stream_result_t s;
     DIAG_CALL(r, gmd_hbm_stream(gpu, k, bytes, iters, 2, &s));
-    r.text("  %-8s %10.3f %10.3f %8s\n", kStreamNames[k], s.tbps_best, s.tbps_median, s.verified ? "ok" : "WRONG");
+    const std::string key = std::string("hbm.") + kStreamNames[k];
+    // the table's rates hold for buffers far beyond the 256 MiB Infinity Cache
+    const double want = bytes >= (1ull << 30) ? e.want(key) : 0;
+    r.text("  %-8s %10.3f %10.3f %10s %8s\n", kStreamNames[k], s.tbps_best, s.tbps_median, want > 0 ? strprintf_local("%.2f", want).c_str() : "-",
+           s.verified ? "ok" : "WRONG");
     obj += std::string(any ? "," : "") + "\"" + kStreamNames[k] + "\":{\"tbps_best\":" + jnum(s.tbps_best) +
-           ",\"tbps_median\":" + jnum(s.tbps_median) + ",\"verified\":" + (s.verified ? "true" : "false") + "}";
+           ",\"tbps_median\":" + jnum(s.tbps_median) + ",\"expected_tbps\":" + (want > 0 ? jnum(want) : "null") + ",\"verified\":" +
+           (s.verified ? "true" : "false") + "}";
     any = true;
+    r.metrics[key] = s.tbps_best;
     if (!s.verified) r.verdict_fail("hbm_stream", GM_HEALTH_WATCH_MEM, s.tbps_best, "stream %s produced wrong data", kStreamNames[k]);
     if (floor_tbps > 0 && s.tbps_best < floor_tbps)
       r.verdict_fail("hbm_stream", GM_HEALTH_WATCH_MEM, s.tbps_best, "stream %s %.3f TB/s is under the %.3f TB/s floor", kStreamNames[k], s.tbps_best, floor_tbps);
+    else if (floor_tbps <= 0)
+      r.grade("hbm_stream", GM_HEALTH_WATCH_MEM, std::string("stream ") + kStreamNames[k], s.tbps_best, want, e, "TB/s");
     worst = std::min(worst, s.tbps_best);
   }
-  if (any) r.verdict_pass("hbm_stream", GM_HEALTH_WATCH_MEM, worst, "every stream kernel verified");
   if (!any) {
     fprintf(stderr, "unknown kernel %s\n", which.c_str());
     return 2;
   }
+  r.verdict_pass("hbm_stream", GM_HEALTH_WATCH_MEM, worst, e.known ? "every stream kernel verified and at its expected rate" : "every stream kernel verified");
   r.member("hbm_stream", obj + "}");
   return 0;
 }
@@ -310,8 +440,9 @@ void progress_cb(double f, const char* what, void* user) {
   if (f >= 1.0) fprintf(stderr, "\n");
 }
 
-int cmd_memtest(const Args& a, Report& r) {
-  const int gpu = (int)a.num("-g", 0);
+int cmd_memtest(const Args& a, Report& r, int gpu) {
+  diag_expect::Expect e;
+  if (!expect_for(a, gpu, &e)) return 2;
   gmd_memtest_config_t c;
   memset(&c, 0, sizeof c);
   c.bytes = a.size("--bytes", 0);
@@ -328,7 +459,7 @@ int cmd_memtest(const Args& a, Report& r) {
         return 2;
       }
     }
-  bool quiet = r.json || !isatty(2);
+  bool quiet = r.json || r.buffered || !isatty(2);
   c.progress = progress_cb;
   c.progress_user = &quiet;
   gmd_memtest_result_t m;
@@ -347,12 +478,19 @@ int cmd_memtest(const Args& a, Report& r) {
                           ",\"patterns\":" + std::to_string(m.patterns_run) + ",\"write_tbps\":" + jnum(m.write_tbps) +
                           ",\"verify_tbps\":" + jnum(m.verify_tbps) + ",\"seconds\":" + jnum(m.seconds) + ",\"log\":" + log + "]}");
   if (m.errors) r.verdict_fail("memtest", GM_HEALTH_WATCH_MEM, (double)m.errors, "memtest found %llu bad words in %.1f GiB", (unsigned long long)m.errors, m.bytes_tested / 1073741824.0);
-  else r.verdict_pass("memtest", GM_HEALTH_WATCH_MEM, 0, "no bad words");
+  // rates: only where the region is large enough for launch costs and the cache not to decide
+  if (m.bytes_tested >= (4ull << 30)) {
+    r.metrics["memtest.write"] = m.write_tbps, r.metrics["memtest.verify"] = m.verify_tbps;
+    r.grade("memtest", GM_HEALTH_WATCH_MEM, "memtest write pass", m.write_tbps, e.want("memtest.write"), e, "TB/s");
+    r.grade("memtest", GM_HEALTH_WATCH_MEM, "memtest verify pass", m.verify_tbps, e.want("memtest.verify"), e, "TB/s");
+  }
+  r.verdict_pass("memtest", GM_HEALTH_WATCH_MEM, 0, "no bad words");
   return 0;
 }
 
-int cmd_mfma(const Args& a, Report& r) {
-  const int gpu = (int)a.num("-g", 0);
+int cmd_mfma(const Args& a, Report& r, int gpu) {
+  diag_expect::Expect e;
+  if (!expect_for(a, gpu, &e)) return 2;
   const std::string which = a.str("--dtype", "all");
   const double secs = a.num("--seconds", 1.0);
   r.text("MFMA pipe peak on GPU %d (%.1f s per dtype)\n  %-6s %12s %12s %10s\n", gpu, secs, "dtype", "TFLOP/s", "best", "MHz");
@@ -367,6 +505,8 @@ int cmd_mfma(const Args& a, Report& r) {
            jnum(m.tflops_best) + ",\"clock_mhz\":" + jnum(m.clock_mhz_est) + "}";
     any = true;
     if (m.verified < 0) r.verdict_fail("mfma_peak", GM_HEALTH_WATCH_COMPUTE, m.tflops, "MFMA %s pipe produced wrong results", kDtypeNames[dt]);
+    r.metrics[std::string("mfma.") + kDtypeNames[dt]] = m.tflops;
+    r.grade("mfma_peak", GM_HEALTH_WATCH_COMPUTE, std::string("matrix-pipe peak ") + kDtypeNames[dt], m.tflops, e.want(std::string("mfma.") + kDtypeNames[dt]), e, "TFLOP/s");
   }
   if (!any) return 2;
   r.verdict_pass("mfma_peak", GM_HEALTH_WATCH_COMPUTE, NAN, "matrix pipes ran");
@@ -449,13 +589,17 @@ struct MfmaWatch {
   }
   // Ends the child and folds the windows of the device with this PCI address; the first window after the
   // start and the last one (cut short by the end of the soak) are left out when there are enough.
-  std::string finish(Report& r, const char* pci_bdf) {
-    if (pid < 0) return "null";
+  void stop() {
+    if (pid < 0) return;
     kill(pid, SIGTERM);
     int st = 0;
     waitpid(pid, &st, 0);
     pid = -1;
     if (reader.joinable()) reader.join();
+  }
+  ~MfmaWatch() { stop(); }
+  std::string fold(Report& r, const char* pci_bdf) {
+    std::lock_guard<std::mutex> l(mu);
     for (auto& kv : bdf_of) {
       if (strcasecmp(kv.second.c_str(), pci_bdf) != 0) continue;
       std::vector<double> v = mfma[kv.first], c = mhz[kv.first];
@@ -478,16 +622,24 @@ struct MfmaWatch {
   }
 };
 
-// Engine-side telemetry of the GPU under stress: power / temperature / clocks at 100 ms.
+// Engine-side telemetry of the GPU under stress: power / temperature / clocks at 100 ms, and what the soak is
+// judged by: the clock it held, how hot it got, whether it could draw its power, whether it throttled thermally.
 struct Soak {
   bool on = false;
   uint32_t gpu = 0;
   int64_t t0 = 0;
+  double power_cap_w = NAN;
   gm_group_t group = 0;
   gm_field_group_t fg = 0;
+  struct Stat {
+    double lo = 1e300, hi = -1e300, sum = 0, first = NAN, last = NAN;
+    int n = 0;
+    double avg() const { return n ? sum / n : NAN; }
+  };
+  std::map<std::string, Stat> stats;
   bool start(int hip_dev) {
-    gmd_device_info_t d;
-    if (gmd_device_info(hip_dev, &d) != GMD_OK) return false;
+    const std::string bdf = bdf_of_hip(hip_dev);
+    if (bdf.empty()) return false;
     gm_init_params_t p;
     memset(&p, 0, sizeof p);
     p.version = GM_INIT_PARAMS_VERSION;
@@ -500,16 +652,18 @@ struct Soak {
       gm_device_attributes_t at;
       memset(&at, 0, sizeof at);
       at.version = GM_DEVICE_ATTRIBUTES_VERSION;
-      if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, d.pci_bdf) == 0) gpu = i, found = true;
+      if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, bdf.c_str()) == 0) gpu = i, found = true, power_cap_w = at.power_cap_w;
     }
     if (!found) {
       gm_shutdown();
       return false;
     }
-    uint16_t ids[] = {GM_FI_POWER_USAGE, GM_FI_GPU_TEMP, GM_FI_MEM_TEMP, GM_FI_GFX_CLOCK, GM_FI_MEM_CLOCK, GM_FI_GFX_UTIL};
-    gm_group_create("diag-soak", &group);
+    uint16_t ids[] = {GM_FI_POWER_USAGE, GM_FI_GPU_TEMP, GM_FI_MEM_TEMP, GM_FI_GFX_CLOCK, GM_FI_MEM_CLOCK, GM_FI_GFX_UTIL,
+                      GM_FI_THERMAL_VIOLATION, GM_FI_POWER_VIOLATION};
+    const std::string name = "diag-soak-" + std::to_string(hip_dev);
+    gm_group_create(name.c_str(), &group);
     gm_group_add_device(group, gpu);
-    gm_field_group_create(ids, 6, "diag-soak", &fg);
+    gm_field_group_create(ids, 8, name.c_str(), &fg);
     gm_watch_fields(group, fg, 100000, 600.0, 0);
     gm_update_all_fields(1);
     struct timespec ts;
@@ -524,8 +678,10 @@ struct Soak {
       uint16_t id;
       const char* name;
       const char* unit;
-    } fs[] = {{GM_FI_POWER_USAGE, "power", "W"},     {GM_FI_GPU_TEMP, "gpu_temp", "C"},   {GM_FI_MEM_TEMP, "hbm_temp", "C"},
-              {GM_FI_GFX_CLOCK, "gfx_clock", "MHz"}, {GM_FI_MEM_CLOCK, "mem_clock", "MHz"}, {GM_FI_GFX_UTIL, "gfx_util", "%"}};
+      bool counter;
+    } fs[] = {{GM_FI_POWER_USAGE, "power", "W", false},     {GM_FI_GPU_TEMP, "gpu_temp", "C", false},   {GM_FI_MEM_TEMP, "hbm_temp", "C", false},
+              {GM_FI_GFX_CLOCK, "gfx_clock", "MHz", false}, {GM_FI_MEM_CLOCK, "mem_clock", "MHz", false}, {GM_FI_GFX_UTIL, "gfx_util", "%", false},
+              {GM_FI_THERMAL_VIOLATION, "thermal_throttle_us", "us", true}, {GM_FI_POWER_VIOLATION, "power_throttle_us", "us", true}};
     std::string obj = "{";
     r.text("  telemetry during the run (100 ms samples):\n");
     bool first = true;
@@ -533,20 +689,67 @@ struct Soak {
       std::vector<gm_value_t> v(8192);
       int n = (int)v.size();
       if (gm_values_since(gpu, f.id, t0, v.data(), &n) != GM_ST_OK) continue;
-      double lo = 1e300, hi = -1e300, sum = 0;
-      int cnt = 0;
+      Stat st;
       for (int i = 0; i < n; i++) {
         if (v[i].status != GM_VS_OK) continue;
         double x = v[i].type == GM_FT_DOUBLE ? v[i].v.dbl : (double)v[i].v.i64;
-        lo = std::min(lo, x), hi = std::max(hi, x), sum += x, cnt++;
+        if (!st.n) st.first = x;
+        st.last = x;
+        st.lo = std::min(st.lo, x), st.hi = std::max(st.hi, x), st.sum += x, st.n++;
       }
-      if (!cnt) continue;
-      r.text("    %-10s min %8.1f  avg %8.1f  max %8.1f %s  (%d samples)\n", f.name, lo, sum / cnt, hi, f.unit, cnt);
-      obj += std::string(first ? "" : ",") + "\"" + f.name + "\":{\"min\":" + jnum(lo) + ",\"avg\":" + jnum(sum / cnt) +
-             ",\"max\":" + jnum(hi) + ",\"samples\":" + std::to_string(cnt) + "}";
+      if (!st.n) continue;
+      stats[f.name] = st;
+      if (f.counter) {
+        r.text("    %-20s grew by %.0f %s  (%d samples)\n", f.name, st.last - st.first, f.unit, st.n);
+        obj += std::string(first ? "" : ",") + "\"" + f.name + "\":{\"delta\":" + jnum(st.last - st.first) + ",\"samples\":" + std::to_string(st.n) + "}";
+      } else {
+        r.text("    %-10s min %8.1f  avg %8.1f  max %8.1f %s  (%d samples)\n", f.name, st.lo, st.avg(), st.hi, f.unit, st.n);
+        obj += std::string(first ? "" : ",") + "\"" + f.name + "\":{\"min\":" + jnum(st.lo) + ",\"avg\":" + jnum(st.avg()) +
+               ",\"max\":" + jnum(st.hi) + ",\"samples\":" + std::to_string(st.n) + "}";
+      }
       first = false;
     }
+    if (std::isfinite(power_cap_w)) obj += std::string(first ? "" : ",") + "\"power_cap\":" + jnum(power_cap_w);
     return obj + "}";
+  }
+  // The soak's verdicts (after summarize).  `seconds` = how long the GPU was under load.
+  void judge(Report& r, const diag_expect::Expect& e, double seconds) {
+    if (!on || !e.known || seconds < 2) return;
+    auto has = [&](const char* k) { return stats.count(k) && stats[k].n > 0; };
+    if (has("gfx_clock")) {
+      const double clk = stats["gfx_clock"].avg();
+      r.metrics["soak.gfx_clock_mhz"] = clk;
+      r.grade("soak_clock", GM_HEALTH_WATCH_POWER, "shader clock held under load", clk, e.want("soak.gfx_clock_mhz"), e, "MHz");
+      r.verdict_pass("soak_clock", GM_HEALTH_WATCH_POWER, clk, strprintf_local("held %.0f MHz under load", clk));
+    }
+    if (has("power")) {
+      r.metrics["soak.power_w"] = stats["power"].avg();
+      if (std::isfinite(power_cap_w) && power_cap_w > 0) {
+        // a healthy part under a matrix load comes close to its cap; one that cannot is held back by something else
+        const double frac = stats["power"].hi / power_cap_w;
+        const int h = diag_expect::grade_rate(frac, e.get("soak.power_fraction"), e);
+        r.verdict("soak_power", GM_HEALTH_WATCH_POWER, h, stats["power"].hi,
+                  strprintf_local("drew at most %.0f W, %.0f %% of the %.0f W cap%s", stats["power"].hi, 100 * frac, power_cap_w,
+                                  h ? strprintf_local(" (expected %.0f %%)", 100 * e.get("soak.power_fraction")).c_str() : ""));
+      }
+    }
+    int h_thermal = GM_HEALTH_PASS;
+    std::string why = "within limits";
+    if (has("gpu_temp")) {
+      const int h = diag_expect::grade_limit(stats["gpu_temp"].hi, e.get("limit.hotspot_c.warn"), e.get("limit.hotspot_c.fail"));
+      if (h > h_thermal) h_thermal = h, why = strprintf_local("hotspot reached %.0f C (warn at %.0f, fail at %.0f)", stats["gpu_temp"].hi, e.get("limit.hotspot_c.warn"), e.get("limit.hotspot_c.fail"));
+    }
+    if (has("hbm_temp")) {
+      const int h = diag_expect::grade_limit(stats["hbm_temp"].hi, e.get("limit.hbm_c.warn"), e.get("limit.hbm_c.fail"));
+      if (h > h_thermal) h_thermal = h, why = strprintf_local("HBM reached %.0f C (warn at %.0f, fail at %.0f)", stats["hbm_temp"].hi, e.get("limit.hbm_c.warn"), e.get("limit.hbm_c.fail"));
+    }
+    if (has("thermal_throttle_us")) {
+      const double frac = (stats["thermal_throttle_us"].last - stats["thermal_throttle_us"].first) / (seconds * 1e6);
+      const int h = diag_expect::grade_limit(frac, e.get("limit.thermal_residency.warn"), e.get("limit.thermal_residency.fail"));
+      if (h > h_thermal) h_thermal = h, why = strprintf_local("thermally throttled for %.1f %% of the soak", 100 * frac);
+    }
+    if (has("gpu_temp") || has("hbm_temp") || has("thermal_throttle_us"))
+      r.verdict("soak_thermal", GM_HEALTH_WATCH_THERMAL, h_thermal, has("gpu_temp") ? stats["gpu_temp"].hi : NAN, why);
   }
   void stop() {
     if (on) gm_shutdown();
@@ -554,53 +757,55 @@ struct Soak {
   }
 };
 
-int cmd_gemm(const Args& a, Report& r) {
-  const int gpu = (int)a.num("-g", 0);
+int cmd_gemm(const Args& a, Report& r, int gpu, MfmaWatch* mfma) {
   const std::string which = a.str("--dtype", "bf16,mxfp8");
   const int m = (int)a.num("--m", 8192), n = (int)a.num("--n", 8192), k = (int)a.num("--k", 8192);
   const double secs = a.num("--seconds", 5.0), floor_tf = a.num("--min-tflops", 0);
-  MfmaWatch mfma;  // started first: a child process, before this one has touched the device
-  const bool want_mfma = a.has("--mfma-counters") && mfma.start();
-  if (a.has("--mfma-counters") && !want_mfma) fprintf(stderr, "note: gpumon-prof-probe not found next to this binary; no matrix-pipe counters\n");
+  diag_expect::Expect e;
+  if (!expect_for(a, gpu, &e)) return 2;
+  const bool table_shape = m == 8192 && n == 8192 && k == 8192;  // the shape the table's rates are for
   Soak soak;
-  if (!a.has("--no-telemetry") && !soak.start(gpu)) fprintf(stderr, "note: engine telemetry unavailable; running without it\n");
+  if (!a.has("--no-telemetry") && !soak.start(gpu)) r.text("  note: engine telemetry unavailable; running without it\n");
   std::string obj = "{";
   bool any = false;
-  auto end_watch = [&] {
-    gmd_device_info_t d;
-    if (want_mfma) r.member("mfma_active", mfma.finish(r, gmd_device_info(gpu, &d) == GMD_OK ? d.pci_bdf : ""));
-  };
+  double loaded_s = 0;
+  const std::string bdf = bdf_of_hip(gpu);
   for (auto& name : csv(which)) {
     int dt = dtype_of(name);
     if (dt < 0 || dt == GMD_DT_F32) {
       fprintf(stderr, "unknown GEMM dtype %s\n", name.c_str());
       soak.stop();
-      end_watch();
       return 2;
     }
+    gmd_gemm_stress_config_t cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = gpu, cfg.dtype = dt, cfg.m = m, cfg.n = n, cfg.k = k, cfg.seconds = secs, cfg.verify = 1;
+    cfg.check_every = (int)a.num("--check-every", 1);
     gmd_mfma_result_t g;
     const double t_begin = MfmaWatch::now();
-    int rc = gmd_gemm_stress(gpu, dt, m, n, k, secs, 1, &g);
+    int rc = gmd_gemm_stress_run(&cfg, &g);
     const double t_end = MfmaWatch::now();
+    loaded_s += t_end - t_begin;
     if (rc != GMD_OK && rc != GMD_ERR_VERIFY) {
       fprintf(stderr, "error: gemm stress -> %d: %s\n", rc, gmd_last_error());
       soak.stop();
-      end_watch();
       return 2;
     }
-    r.text("GEMM stress %s %dx%dx%d on GPU %d: %.1f TFLOP/s (best %.1f), %llu launches in %.1f s, sdc mismatches %llu, "
+    const std::string key = "gemm." + name;
+    const double want = table_shape ? e.want(key) : 0;
+    r.text("GEMM stress %s %dx%dx%d on GPU %d: %.1f TFLOP/s (best %.1f%s), %llu launches in %.1f s, sdc mismatches %llu, "
            "max rel err vs fp32 reference %.2e, check %s\n",
-           name.c_str(), m, n, k, gpu, g.tflops, g.tflops_best, (unsigned long long)g.launches, g.seconds,
-           (unsigned long long)g.sdc_mismatches, g.max_rel_err, g.verified > 0 ? "ok" : g.verified < 0 ? "WRONG" : "skipped");
+           name.c_str(), m, n, k, gpu, g.tflops, g.tflops_best, want > 0 ? strprintf_local(", expected %.0f", want).c_str() : "",
+           (unsigned long long)g.launches, g.seconds, (unsigned long long)g.sdc_mismatches, g.max_rel_err,
+           g.verified > 0 ? "ok" : g.verified < 0 ? "WRONG" : "skipped");
     obj += std::string(any ? "," : "") + "\"" + name + "\":{\"tflops\":" + jnum(g.tflops) + ",\"tflops_best\":" +
-           jnum(g.tflops_best) + ",\"launches\":" + std::to_string(g.launches) + ",\"sdc_mismatches\":" +
-           std::to_string(g.sdc_mismatches) + ",\"max_rel_err\":" + jnum(g.max_rel_err) + ",\"verified\":" +
+           jnum(g.tflops_best) + ",\"expected_tflops\":" + (want > 0 ? jnum(want) : "null") + ",\"launches\":" + std::to_string(g.launches) +
+           ",\"sdc_mismatches\":" + std::to_string(g.sdc_mismatches) + ",\"max_rel_err\":" + jnum(g.max_rel_err) + ",\"verified\":" +
            std::to_string(g.verified);
-    if (want_mfma) {  // the windows that lie inside this dtype's soak
+    if (mfma) {  // the windows that lie inside this dtype's soak
       usleep(300000);  // let the window that ends with the soak arrive
-      gmd_device_info_t d;
       int wn = 0;
-      const double avg = gmd_device_info(gpu, &d) == GMD_OK ? mfma.average_between(d.pci_bdf, t_begin, t_end, &wn) : -1.0;
+      const double avg = mfma->average_between(bdf.c_str(), t_begin, t_end, &wn);
       if (wn > 0) {
         r.text("  matrix pipes during the %s soak: %.1f %% busy (MFMA busy counter, %d windows)\n", name.c_str(), avg, wn);
         obj += ",\"mfma_active_avg\":" + jnum(avg);
@@ -608,6 +813,7 @@ int cmd_gemm(const Args& a, Report& r) {
     }
     obj += "}";
     any = true;
+    r.metrics[key] = g.tflops;
     const std::string test = "gemm_" + name;
     if (g.verified < 0 && !g.sdc_mismatches)
       r.verdict_fail(test, GM_HEALTH_WATCH_COMPUTE, g.max_rel_err,
@@ -617,22 +823,85 @@ int cmd_gemm(const Args& a, Report& r) {
                      "GEMM %s: %llu launches changed their checksum (silent data corruption)", name.c_str(), (unsigned long long)g.sdc_mismatches);
     if (floor_tf > 0 && g.tflops < floor_tf)
       r.verdict_fail(test, GM_HEALTH_WATCH_COMPUTE, g.tflops, "GEMM %s %.1f TFLOP/s is under the %.1f floor", name.c_str(), g.tflops, floor_tf);
+    else if (floor_tf <= 0)
+      r.grade(test, GM_HEALTH_WATCH_COMPUTE, "GEMM " + name, g.tflops, want, e, "TFLOP/s");
     r.verdict_pass(test, GM_HEALTH_WATCH_COMPUTE, g.tflops, strprintf_local("%.1f TFLOP/s, reference and checksums agree", g.tflops));
   }
   r.member("gemm_stress", obj + "}");
   r.member("telemetry", soak.summarize(r));
+  soak.judge(r, e, loaded_s);
   soak.stop();
-  end_watch();
   return 0;
 }
 
 bool parse_gpus(const Args& a, std::vector<int>* ids) {
-  if (!a.has("--gpus")) return true;
+  if (!a.has("--gpus") || a.str("--gpus") == "all") return true;
   for (auto& s : csv(a.str("--gpus"))) ids->push_back(atoi(s.c_str()));
   return !ids->empty();
 }
 
-int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, std::string* js) {
+// Which physical link of a GPU leads to which peer, from the engine's link table (matched by PCI address, since
+// the compute runtime and the engine may number the cards differently).
+struct LinkMap {
+  bool on = false;
+  std::vector<int> engine_of;  // device-list position -> engine GPU index, -1 unknown
+  std::vector<std::vector<gm_xgmi_link_t>> links;  // per position
+  double per_direction_gbytes = 0;  // advertised rate of one direction of one link, GB/s; 0 unknown
+
+  void load(const std::vector<int>& hip_ids) {
+    gm_init_params_t p;
+    memset(&p, 0, sizeof p);
+    p.version = GM_INIT_PARAMS_VERSION;
+    p.mode = GM_MODE_EMBEDDED;
+    if (gm_init(&p) != GM_ST_OK) return;
+    on = true;
+    uint32_t n = 0;
+    gm_device_count(&n);
+    for (int hip : hip_ids) {
+      int idx = -1;
+      const std::string bdf = bdf_of_hip(hip);
+      for (uint32_t i = 0; i < n && idx < 0 && !bdf.empty(); i++) {
+        gm_device_attributes_t at;
+        memset(&at, 0, sizeof at);
+        at.version = GM_DEVICE_ATTRIBUTES_VERSION;
+        if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, bdf.c_str()) == 0) idx = (int)i;
+      }
+      engine_of.push_back(idx);
+      std::vector<gm_xgmi_link_t> l(64);
+      int cnt = (int)l.size();
+      if (idx < 0 || gm_xgmi_links((uint32_t)idx, l.data(), &cnt) != GM_ST_OK) cnt = 0;
+      l.resize(cnt);
+      for (auto& x : l)
+        if (x.max_bandwidth_gbps > 0) per_direction_gbytes = std::max(per_direction_gbytes, x.max_bandwidth_gbps / 8.0);
+      links.push_back(l);
+    }
+    gm_shutdown();
+  }
+  // Link index on position i whose far end is position j; -1 when the platform does not say.
+  int link_to(int i, int j) const {
+    if (!on || i >= (int)links.size() || j >= (int)engine_of.size() || engine_of[j] < 0) return -1;
+    for (auto& x : links[i])
+      if (x.peer_gpu == engine_of[j]) return (int)x.link;
+    return -1;
+  }
+};
+
+// What the fabric of this node is expected to carry: the advertised rate of one direction of one link from the
+// engine's link table (or --link-gbps, or the MI355X figure), the deratings of gmd_link_expect_t.
+gmd_link_expect_t fabric_expect(const Args& a, const std::vector<int>& ids, LinkMap* map) {
+  gmd_link_expect_t e;
+  memset(&e, 0, sizeof e);
+  if (map && !map->on) map->load(ids);
+  if (a.has("--link-gbps")) e.link_gbps = a.num("--link-gbps", 0);
+  else if (map && map->per_direction_gbytes > 0) e.link_gbps = map->per_direction_gbytes;
+  e.warn_ratio = a.num("--warn-ratio", 0);
+  e.fail_ratio = a.num("--fail-ratio", 0);
+  e.scale = a.num("--expect-scale", 1.0);
+  gmd_link_expect_defaults(&e);
+  return e;
+}
+
+int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, const gmd_link_expect_t& fe, std::string* js) {
   gmd_rccl_config_t c;
   memset(&c, 0, sizeof c);
   c.ndev = (int)ids.size();
@@ -656,16 +925,17 @@ int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, std::string
   int n = (int)pts.size();
   DIAG_CALL(r, gmd_rccl_sweep(&c, pts.data(), &n));
   double peak[GMD_COLL_COUNT] = {0};
+  uint64_t peak_bytes[GMD_COLL_COUNT] = {0};
   int w = n ? pts[0].ndev : 0;
-  r.text("# RCCL sweep on %d GPU%s\n# %-15s%14s%7s%12s%13s%13s  check\n", w, w == 1 ? "" : "s", "op", "bytes", "iters", "time(us)",
-         "algbw(GB/s)", "busbw(GB/s)");
+  r.text("# RCCL sweep on %d GPU%s (device-side timing; rows under about 1 MiB are bound by launch latency, not by the links)\n"
+         "# %-15s%14s%7s%12s%13s%13s  check\n", w, w == 1 ? "" : "s", "op", "bytes", "iters", "time(us)", "algbw(GB/s)", "busbw(GB/s)");
   // gmd_rccl_sweep fails unless every communicator reports exactly the requested rank count on its own device
-  *js += "{\"gpus\":" + std::to_string(w) + ",\"communicator_ranks\":" + std::to_string(w) + ",\"points\":[";
+  *js += "{\"gpus\":" + std::to_string(w) + ",\"communicator_ranks\":" + std::to_string(w) + ",\"timing\":\"device events; rows under about 1 MiB are launch-latency bound\",\"points\":[";
   for (int i = 0; i < n; i++) {
     auto& p = pts[i];
     r.text("  %-15s%14llu%7d%12.1f%13.2f%13.2f  %s\n", gmd_collective_name(p.op), (unsigned long long)p.bytes, p.iters, p.time_us,
            p.algbw_gbps, p.busbw_gbps, p.verified > 0 ? "ok" : p.verified < 0 ? "MISMATCH" : "-");
-    peak[p.op] = std::max(peak[p.op], p.busbw_gbps);
+    if (p.busbw_gbps > peak[p.op]) peak[p.op] = p.busbw_gbps, peak_bytes[p.op] = p.bytes;
     *js += std::string(i ? "," : "") + "{\"op\":" + jstr(gmd_collective_name(p.op)) + ",\"bytes\":" + std::to_string(p.bytes) +
            ",\"time_us\":" + jnum(p.time_us) + ",\"algbw_gbps\":" + jnum(p.algbw_gbps) + ",\"busbw_gbps\":" + jnum(p.busbw_gbps) +
            ",\"verified\":" + std::to_string(p.verified) + "}";
@@ -683,37 +953,56 @@ int run_sweep(const Args& a, Report& r, const std::vector<int>& ids, std::string
     first = false;
   }
   r.text("\n");
-  *js += "}}";
-  // A floor only means something once links are involved: the 1-GPU row is a local copy.
+  *js += "},\"expected_busbw_gbps\":{";
+  // Expectations only mean something once links are involved (the 1-GPU row is a local copy) and once the sweep
+  // reached sizes at which the links, not the launches, decide.
   const double floor_gbps = a.num("--min-busbw", 0);
-  if (floor_gbps > 0 && w > 1)
-    for (int i = 0; i < GMD_COLL_COUNT; i++)
-      if (peak[i] > 0 && peak[i] < floor_gbps)
+  const bool graded = w > 1 && !a.has("--no-expect") && c.max_bytes >= (64ull << 20);
+  first = true;
+  for (int i = 0; i < GMD_COLL_COUNT; i++) {
+    if (peak[i] <= 0 || w < 2) continue;
+    const double want = floor_gbps > 0 ? floor_gbps : gmd_rccl_expected_busbw(&fe, i, w);
+    *js += std::string(first ? "" : ",") + "\"" + gmd_collective_name(i) + "\":" + jnum(want);
+    first = false;
+    if (floor_gbps > 0) {
+      if (peak[i] < floor_gbps)
         r.verdict_fail("rccl", GM_HEALTH_WATCH_XGMI, peak[i], "%s peaks at %.1f GB/s bus bandwidth on %d GPUs, under the %.1f GB/s floor",
                        gmd_collective_name(i), peak[i], w, floor_gbps);
-  r.verdict_pass("rccl", GM_HEALTH_WATCH_XGMI, NAN, "every collective returned the right data");
+    } else if (graded) {
+      const int h = gmd_grade_against(peak[i], want, fe.warn_ratio, fe.fail_ratio);
+      if (h)
+        r.verdict("rccl", GM_HEALTH_WATCH_XGMI, h, peak[i],
+                  strprintf_local("%s peaks at %.1f GB/s bus bandwidth on %d GPUs (at %llu bytes), %.0f %% of the %.1f GB/s expected of %.1f GB/s links",
+                                  gmd_collective_name(i), peak[i], w, (unsigned long long)peak_bytes[i], 100 * peak[i] / want, want, fe.link_gbps));
+    }
+  }
+  *js += "}}";
+  r.verdict_pass("rccl", GM_HEALTH_WATCH_XGMI, NAN, graded || floor_gbps > 0 ? "every collective returned the right data at its expected bus bandwidth"
+                                                                               : "every collective returned the right data");
   return 0;
 }
 
 int cmd_rccl(const Args& a, Report& r) {
   std::vector<int> ids;
   if (!parse_gpus(a, &ids)) return 2;
+  int visible = gmd_device_count();
+  if (ids.empty())
+    for (int i = 0; i < visible; i++) ids.push_back(i);
+  LinkMap map;
+  const gmd_link_expect_t fe = ids.size() > 1 ? fabric_expect(a, ids, &map) : fabric_expect(a, ids, nullptr);
   if (!a.has("--scaling")) {
     std::string js;
-    int rc = run_sweep(a, r, ids, &js);
+    int rc = run_sweep(a, r, ids, fe, &js);
     if (rc) return rc;
     r.member("rccl", js);
     return 0;
   }
   // 1 / 2 / 4 / 8 ... GPUs: the scaling series.
-  int visible = gmd_device_count();
-  if (ids.empty())
-    for (int i = 0; i < visible; i++) ids.push_back(i);
   std::string arr = "[";
   for (size_t w = 1; w <= ids.size(); w *= 2) {
     std::vector<int> sub(ids.begin(), ids.begin() + w);
     std::string js;
-    int rc = run_sweep(a, r, sub, &js);
+    int rc = run_sweep(a, r, sub, fe, &js);
     if (rc) return rc;
     arr += std::string(w > 1 ? "," : "") + js;
   }
@@ -721,54 +1010,18 @@ int cmd_rccl(const Args& a, Report& r) {
   return 0;
 }
 
-// Which physical link of a GPU leads to which peer, from the engine's link table (matched by PCI address, since
-// the compute runtime and the engine may number the cards differently).
-struct LinkMap {
-  bool on = false;
-  std::vector<int> engine_of;  // device-list position -> engine GPU index, -1 unknown
-  std::vector<std::vector<gm_xgmi_link_t>> links;  // per position
-  double per_direction_gbytes = 0;  // advertised rate of one direction of one link, GB/s; 0 unknown
-
-  void load(const std::vector<int>& hip_ids) {
-    gm_init_params_t p;
-    memset(&p, 0, sizeof p);
-    p.version = GM_INIT_PARAMS_VERSION;
-    p.mode = GM_MODE_EMBEDDED;
-    if (gm_init(&p) != GM_ST_OK) return;
-    on = true;
-    uint32_t n = 0;
-    gm_device_count(&n);
-    for (int hip : hip_ids) {
-      int idx = -1;
-      gmd_device_info_t d;
-      if (gmd_device_info(hip, &d) == GMD_OK)
-        for (uint32_t i = 0; i < n && idx < 0; i++) {
-          gm_device_attributes_t at;
-          memset(&at, 0, sizeof at);
-          at.version = GM_DEVICE_ATTRIBUTES_VERSION;
-          if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, d.pci_bdf) == 0) idx = (int)i;
-        }
-      engine_of.push_back(idx);
-      std::vector<gm_xgmi_link_t> l(64);
-      int cnt = (int)l.size();
-      if (idx < 0 || gm_xgmi_links((uint32_t)idx, l.data(), &cnt) != GM_ST_OK) cnt = 0;
-      l.resize(cnt);
-      for (auto& x : l)
-        if (x.max_bandwidth_gbps > 0) per_direction_gbytes = std::max(per_direction_gbytes, x.max_bandwidth_gbps / 8.0);
-      links.push_back(l);
-    }
-    gm_shutdown();
+std::string matrix_json(const std::vector<double>& m, int w) {
+  std::string mj = "[";
+  for (int i = 0; i < w; i++) {
+    mj += std::string(i ? "," : "") + "[";
+    for (int j = 0; j < w; j++) mj += std::string(j ? "," : "") + jnum(m[(size_t)i * w + j]);
+    mj += "]";
   }
-  // Link index on position i whose far end is position j; -1 when the platform does not say.
-  int link_to(int i, int j) const {
-    if (!on || i >= (int)links.size() || j >= (int)engine_of.size() || engine_of[j] < 0) return -1;
-    for (auto& x : links[i])
-      if (x.peer_gpu == engine_of[j]) return (int)x.link;
-    return -1;
-  }
-};
+  return mj + "]";
+}
 
-// xGMI link test: the peer-store matrix in three traffic patterns, graded per link.
+// xGMI link test: the peer-copy matrix in three traffic patterns, with remote stores and with remote loads,
+// read together into findings that name the GPU, the link and the peer.
 int cmd_links(const Args& a, Report& r) {
   std::vector<int> ids;
   if (!parse_gpus(a, &ids)) return 2;
@@ -780,17 +1033,33 @@ int cmd_links(const Args& a, Report& r) {
     return 2;
   }
   if (w == 1) {
-    r.text("# xGMI link test: one GPU visible, no link to test\n");
-    r.member("links", "{\"gpus\":1,\"tested\":0}");
+    // No link to test: prove the fused all-peers launch and its two clocks inside the one GPU instead.
+    const int stand_ins = 7;
+    std::vector<double> g(stand_ins);
+    std::vector<uint64_t> bad(stand_ins);
+    gmd_link_fan_result_t fr;
+    DIAG_CALL(r, gmd_link_fan_selftest(ids[0], stand_ins, a.size("--bytes", 64ull << 20), (int)a.num("--workgroups", 0), (int)a.num("--iters", 5), g.data(),
+                                       bad.data(), &fr));
+    uint64_t nbad = 0;
+    for (auto b : bad) nbad += b;
+    const bool clocks_agree = fr.window_ms_max <= fr.launch_ms * 1.02 + 0.05 && fr.window_ms_min > 0;
+    r.text("# xGMI link test: one GPU visible, no link to test\n# self-test of the all-peers launch on GPU %d: %d local destinations, %.1f GB/s in total, "
+           "per-destination windows %.2f..%.2f ms inside a %.2f ms launch, %llu bad words\n",
+           ids[0], stand_ins, fr.launch_gbps, fr.window_ms_min, fr.window_ms_max, fr.launch_ms, (unsigned long long)nbad);
+    r.member("links", "{\"gpus\":1,\"tested\":0,\"selftest\":{\"destinations\":" + std::to_string(stand_ins) + ",\"launch_gbps\":" + jnum(fr.launch_gbps) +
+                          ",\"launch_ms\":" + jnum(fr.launch_ms) + ",\"window_ms_min\":" + jnum(fr.window_ms_min) + ",\"window_ms_max\":" +
+                          jnum(fr.window_ms_max) + ",\"bad_words\":" + std::to_string(nbad) + "}}");
     r.member("p2p_gbps", "[[0]]");
+    if (nbad) r.verdict_fail("xgmi_p2p", GM_HEALTH_WATCH_XGMI, (double)nbad, "link-test self-test: %llu corrupt words inside GPU %d", (unsigned long long)nbad, ids[0]);
+    if (!clocks_agree)
+      r.verdict_fail("xgmi_p2p", GM_HEALTH_WATCH_XGMI, fr.window_ms_max, "link-test self-test: stamp windows (%.3f..%.3f ms) do not fit the %.3f ms launch",
+                     fr.window_ms_min, fr.window_ms_max, fr.launch_ms);
     return 0;
   }
   LinkMap map;
-  map.load(ids);
-  // Absolute floor for one direction of one link: half the advertised rate unless given.  (The advertised rate is
-  // lanes x bit rate; protocol overhead and the store path keep a healthy link well above half of it.)
-  double floor = a.has("--floor-gbps") ? a.num("--floor-gbps", 0) : 0.5 * (map.per_direction_gbytes > 0 ? map.per_direction_gbytes : 76.0);
-  gmd_link_rule_t rule = {floor, a.num("--warn-ratio", 0), a.num("--fail-ratio", 0)};
+  gmd_link_expect_t fe = fabric_expect(a, ids, &map);
+  // --floor-gbps replaces the expectation of one direction of one link outright (and scales the others with it)
+  if (a.has("--floor-gbps") && a.num("--floor-gbps", 0) > 0) fe.scale *= a.num("--floor-gbps", 0) / (fe.fail_ratio * gmd_link_expected_gbps(&fe, GMD_LINK_UNI, 1));
 
   gmd_link_config_t c;
   memset(&c, 0, sizeof c);
@@ -802,47 +1071,81 @@ int cmd_links(const Args& a, Report& r) {
   c.workgroups = (int)a.num("--workgroups", 0);
 
   const char* names[] = {"uni", "bidi", "all"};
-  const char* what[] = {"one pair at a time", "both directions of a pair at once", "every GPU to every peer at once"};
+  const char* what[] = {"one pair at a time", "both directions of a pair at once", "every GPU on every peer at once"};
   std::vector<std::string> modes = a.has("--modes") ? csv(a.str("--modes")) : std::vector<std::string>{"uni", "bidi", "all"};
-  std::string js = "{\"gpus\":" + std::to_string(w) + ",\"floor_gbps\":" + jnum(floor);
+  const std::string direction = a.str("--direction", "both");
+  if (direction != "push" && direction != "pull" && direction != "both") {
+    fprintf(stderr, "--direction takes push, pull or both\n");
+    return 2;
+  }
+  std::string js = "{\"gpus\":" + std::to_string(w) + ",\"link_gbps\":" + jnum(fe.link_gbps) + ",\"warn_ratio\":" + jnum(fe.warn_ratio) +
+                   ",\"fail_ratio\":" + jnum(fe.fail_ratio);
   std::vector<int> worst(w, GM_HEALTH_PASS);
   std::vector<std::string> worst_msg(w);
   std::vector<double> slowest(w, 1e300);
-  for (int mode = 0; mode < 3; mode++) {
-    if (std::find(modes.begin(), modes.end(), names[mode]) == modes.end()) continue;
-    std::vector<double> m((size_t)w * w);
-    std::vector<uint64_t> bad((size_t)w * w);
-    DIAG_CALL(r, gmd_link_test(&c, mode, m.data(), bad.data()));
-    r.text("# link bandwidth, GB/s, %s (row = source GPU)\n", what[mode]);
-    std::string mj = "[";
-    for (int i = 0; i < w; i++) {
-      mj += std::string(i ? "," : "") + "[";
-      r.text("  ");
-      for (int j = 0; j < w; j++) {
-        r.text("%8.1f", m[(size_t)i * w + j]);
-        mj += std::string(j ? "," : "") + jnum(m[(size_t)i * w + j]);
+  std::string findings = "[";
+  int n_findings = 0;
+  for (int pull = 0; pull < 2; pull++) {
+    if ((pull && direction == "push") || (!pull && direction == "pull")) continue;
+    c.pull = pull;
+    fe.pull = pull;
+    std::vector<double> mat[3], egress(w, 0);
+    std::vector<uint64_t> bad_total((size_t)w * w, 0);
+    js += std::string(",\"") + (pull ? "pull" : "push") + "\":{\"expected_gbps\":{";
+    for (int mode = 0; mode < 3; mode++)
+      js += std::string(mode ? "," : "") + "\"" + names[mode] + "\":" + jnum(gmd_link_expected_gbps(&fe, mode, 1));
+    js += "}";
+    for (int mode = 0; mode < 3; mode++) {
+      // the one-at-a-time matrix is what the others are read against: it always runs
+      if (mode != GMD_LINK_UNI && std::find(modes.begin(), modes.end(), names[mode]) == modes.end()) continue;
+      std::vector<double>& m = mat[mode];
+      m.assign((size_t)w * w, 0);
+      std::vector<uint64_t> bad((size_t)w * w);
+      c.per_gpu_gbps = mode == GMD_LINK_ALL ? egress.data() : nullptr;
+      DIAG_CALL(r, gmd_link_test(&c, mode, m.data(), bad.data()));
+      for (size_t x = 0; x < bad.size(); x++) bad_total[x] += bad[x];
+      r.text("# link bandwidth, GB/s, %s, %s (row = GPU that runs the copy; expected %.1f per link)\n", pull ? "remote loads" : "remote stores", what[mode],
+             gmd_link_expected_gbps(&fe, mode, 1));
+      for (int i = 0; i < w; i++) {
+        r.text("  ");
+        for (int j = 0; j < w; j++) {
+          r.text("%8.1f", m[(size_t)i * w + j]);
+          if (i != j && m[(size_t)i * w + j] >= 0) slowest[i] = std::min(slowest[i], m[(size_t)i * w + j]);
+        }
+        if (mode == GMD_LINK_ALL) r.text("   | %8.1f by the launch's own clock", egress[i]);
+        r.text("\n");
       }
-      r.text("\n");
-      mj += "]";
+      js += std::string(",\"") + names[mode] + "\":" + matrix_json(m, w);
+      if (mode == GMD_LINK_ALL) {
+        js += ",\"per_gpu_gbps\":[";
+        for (int i = 0; i < w; i++) js += std::string(i ? "," : "") + jnum(egress[i]);
+        js += "]";
+      }
+      if (mode == GMD_LINK_UNI && !pull) r.member("p2p_gbps", matrix_json(m, w));
     }
-    js += std::string(",\"") + names[mode] + "\":" + mj + "]";
-    if (mode == GMD_LINK_UNI) r.member("p2p_gbps", mj + "]");
-    // The floor is one direction's; with both directions or all links busy a healthy link keeps most of it.
-    gmd_link_rule_t mr = rule;
-    mr.floor_gbps = mode == GMD_LINK_UNI ? floor : mode == GMD_LINK_BIDI ? 0.8 * floor : 0;
-    std::vector<gmd_link_verdict_t> v((size_t)w * (w - 1));
-    int nv = (int)v.size();
-    int rc = gmd_link_grade(w, m.data(), c.verify ? bad.data() : nullptr, &mr, v.data(), &nv);
+    js += "}";
+    std::vector<gmd_link_finding_t> f((size_t)w * w * 3 + 2 * w);
+    int nf = (int)f.size();
+    int rc = gmd_link_diagnose(w, mat[0].data(), mat[1].empty() ? nullptr : mat[1].data(), mat[2].empty() ? nullptr : mat[2].data(),
+                               c.verify ? bad_total.data() : nullptr, &fe, f.data(), &nf);
     if (rc < 0) return 2;
-    for (int k = 0; k < nv; k++) {
-      const int link = map.link_to(v[k].src, v[k].dst);
-      std::string where = "link " + (link >= 0 ? std::to_string(link) : std::string("?")) + " to GPU " + std::to_string(ids[v[k].dst]) +
-                          " (" + names[mode] + "): " + v[k].message;
-      if (v[k].health != GM_HEALTH_PASS) r.text("  %s GPU %d %s\n", v[k].health == GM_HEALTH_FAIL ? "FAIL" : "WARN", ids[v[k].src], where.c_str());
-      if (v[k].gbps >= 0) slowest[v[k].src] = std::min(slowest[v[k].src], v[k].gbps);
-      if (v[k].health > worst[v[k].src]) worst[v[k].src] = v[k].health, worst_msg[v[k].src] = where;
+    for (int k = 0; k < nf; k++) {
+      // the GPU a finding is charged to: the one that ran the copy, or for a slow receiver the peer itself
+      const int pos = f[k].src >= 0 ? f[k].src : f[k].dst;
+      const int link = f[k].src >= 0 && f[k].dst >= 0 ? map.link_to(f[k].src, f[k].dst) : -1;
+      std::string where = gmd_link_finding_name(f[k].kind);
+      if (f[k].src >= 0 && f[k].dst >= 0) where += ", link " + (link >= 0 ? std::to_string(link) : std::string("?")) + " to GPU " + std::to_string(ids[f[k].dst]);
+      where += std::string(" (") + (pull ? "pull, " : "push, ") + names[f[k].mode] + "): " + f[k].message;
+      r.text("  %s GPU %d %s\n", f[k].health >= GM_HEALTH_FAIL ? "FAIL" : "WARN", ids[pos], where.c_str());
+      if (f[k].health > worst[pos]) worst[pos] = f[k].health, worst_msg[pos] = where;
+      findings += std::string(n_findings++ ? "," : "") + "{\"kind\":\"" + gmd_link_finding_name(f[k].kind) + "\",\"direction\":\"" + (pull ? "pull" : "push") +
+                  "\",\"pattern\":\"" + names[f[k].mode] + "\",\"gpu\":" + std::to_string(ids[pos]) + ",\"pci_bdf\":" + jstr(bdf_of_hip(ids[pos])) +
+                  ",\"link\":" + (link >= 0 ? std::to_string(link) : std::string("null")) + ",\"peer\":" +
+                  (f[k].src >= 0 && f[k].dst >= 0 ? std::to_string(ids[f[k].dst]) : std::string("null")) + ",\"health\":" + std::to_string(f[k].health) +
+                  ",\"gbps\":" + jnum(f[k].gbps) + ",\"expected_gbps\":" + jnum(f[k].expected_gbps) + ",\"message\":" + jstr(f[k].message) + "}";
     }
   }
+  js += ",\"findings\":" + findings + "]";
   // link -> peer table, so that a verdict can be traced to a cable
   std::string lj = "[";
   bool any = false;
@@ -861,7 +1164,153 @@ int cmd_links(const Args& a, Report& r) {
   return 0;
 }
 
-int cmd_run(const Args& a, Report& r) {
+// ---------------------------------------------------------------- several GPUs at once --
+// One host thread per GPU runs the same test at the same time, so the node's power delivery and cooling carry
+// all GPUs' load together; afterwards every GPU's rates are held against the median of the others.
+using GpuTest = std::function<int(const Args&, Report&, int)>;
+
+int run_on(const Args& a, Report& r, const std::vector<int>& gpus, const GpuTest& fn) {
+  if (gpus.size() == 1) {  // one GPU: the report is that GPU's
+    r.gpu = gpus[0];
+    r.pci_bdf = bdf_of_hip(gpus[0]);
+    return fn(a, r, gpus[0]);
+  }
+  if (r.subs.empty()) {
+    r.subs.resize(gpus.size());
+    for (size_t i = 0; i < gpus.size(); i++) {
+      r.subs[i].gpu = gpus[i];
+      r.subs[i].pci_bdf = bdf_of_hip(gpus[i]);  // also: every device touched once from this thread before the others start
+      r.subs[i].json = r.json;
+      r.subs[i].buffered = true;
+    }
+  }
+  std::vector<int> rcs(gpus.size(), 0);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < gpus.size(); i++) th.emplace_back([&, i] { rcs[i] = fn(a, r.subs[i], gpus[i]); });
+  for (auto& t : th) t.join();
+  int rc = 0;
+  for (size_t i = 0; i < gpus.size(); i++) {
+    if (!r.json && !r.subs[i].out.empty()) {
+      printf("=== GPU %d (%s)\n%s", gpus[i], r.subs[i].pci_bdf.c_str(), r.subs[i].out.c_str());
+      r.subs[i].out.clear();
+    }
+    if (rcs[i]) rc = rcs[i];
+    r.failed = r.failed || r.subs[i].failed;
+    r.warned = r.warned || r.subs[i].warned;
+  }
+  return rc;
+}
+
+// Every rate the GPUs measured, each GPU against the median of the others, and what the node drew in total.
+void compare_gpus(const Args& a, Report& r) {
+  const size_t n = r.subs.size();
+  if (n < 2) return;
+  const double warn = a.num("--outlier-warn", 0.95), fail = a.num("--outlier-fail", 0.90);
+  std::map<std::string, int> keys;
+  for (auto& s : r.subs)
+    for (auto& kv : s.metrics) keys[kv.first]++;
+  std::string cj = "{";
+  bool first = true;
+  r.text("=== node: every GPU against the median of the others (warn under %.0f %%, fail under %.0f %%)\n", 100 * warn, 100 * fail);
+  for (auto& kc : keys) {
+    const std::string& key = kc.first;
+    if (kc.second < 2 || key == "soak.power_w") continue;
+    std::vector<double> v(n, NAN), med(n, 0);
+    std::vector<int32_t> h(n, 0);
+    for (size_t i = 0; i < n; i++)
+      if (r.subs[i].metrics.count(key)) v[i] = r.subs[i].metrics[key];
+    gmd_outlier_grade((int)n, v.data(), warn, fail, h.data(), med.data());
+    cj += std::string(first ? "" : ",") + "\"" + key + "\":[";
+    first = false;
+    r.text("  %-22s", key.c_str());
+    for (size_t i = 0; i < n; i++) {
+      cj += std::string(i ? "," : "") + jnum(v[i]);
+      r.text(" %9.4g%s", v[i], h[i] >= GM_HEALTH_FAIL ? "!!" : h[i] ? "! " : "  ");
+      if (!std::isfinite(v[i])) continue;
+      const uint32_t system = key.rfind("hbm.", 0) == 0 || key.rfind("memtest.", 0) == 0 ? GM_HEALTH_WATCH_MEM
+                              : key.rfind("soak.", 0) == 0                                 ? GM_HEALTH_WATCH_POWER
+                                                                                           : GM_HEALTH_WATCH_COMPUTE;
+      if (h[i])
+        r.subs[i].verdict("peer_compare", system, h[i], v[i],
+                          strprintf_local("%s %.4g is %.1f %% of the other GPUs' median %.4g under the same load", key.c_str(), v[i], 100 * v[i] / med[i], med[i]));
+    }
+    r.text("\n");
+  }
+  for (auto& s : r.subs) {
+    s.verdict("peer_compare", GM_HEALTH_WATCH_COMPUTE, GM_HEALTH_PASS, NAN, "in line with the other GPUs of the node");
+    r.failed = r.failed || s.failed;
+    r.warned = r.warned || s.warned;
+    if (!r.json && !s.out.empty()) fputs(s.out.c_str(), stdout), s.out.clear();
+  }
+  cj += "}";
+  double power = 0, clk_lo = 1e300;
+  int np = 0, lo_gpu = -1;
+  for (auto& s : r.subs) {
+    if (s.metrics.count("soak.power_w")) power += s.metrics["soak.power_w"], np++;
+    if (s.metrics.count("soak.gfx_clock_mhz") && s.metrics["soak.gfx_clock_mhz"] < clk_lo) clk_lo = s.metrics["soak.gfx_clock_mhz"], lo_gpu = s.gpu;
+  }
+  std::string nj = "{\"gpus\":" + std::to_string(n) + ",\"compare\":" + cj;
+  if (np) {
+    r.text("  node power under load: %.0f W over %d GPUs; lowest sustained clock %.0f MHz on GPU %d\n", power, np, clk_lo, lo_gpu);
+    nj += ",\"power_w\":" + jnum(power) + ",\"lowest_clock_mhz\":" + jnum(clk_lo) + ",\"lowest_clock_gpu\":" + std::to_string(lo_gpu);
+  }
+  r.member("node", nj + "}");
+}
+
+// gpumon-diag expect [--arch gfx950] [--name "AMD Instinct MI355X"] [--expect ..] [--expect-scale F] [--check key=value,..]
+// What a GPU is held against, without needing one: the table entry for an architecture / product name (default:
+// GPU 0 when one is visible, else gfx950), and with --check the grade of given measurements.
+int cmd_expect(const Args& a, Report& r) {
+  std::string arch = a.str("--arch"), name = a.str("--name");
+  if (arch.empty()) {
+    gmd_device_info_t d;
+    if (gmd_device_count() > 0 && gmd_device_info((int)a.num("-g", 0), &d) == GMD_OK) arch = d.gcn_arch, name = d.name;
+    else arch = "gfx950";
+  }
+  diag_expect::Expect e = a.has("--no-expect") ? diag_expect::Expect() : diag_expect::lookup(arch, name);
+  std::string bad;
+  if (a.has("--expect") && !diag_expect::apply_overrides(a.str("--expect"), &e, &bad)) {
+    fprintf(stderr, "--expect: cannot read '%s' (key=value, value >= 0)\n", bad.c_str());
+    return 2;
+  }
+  e.scale = a.num("--expect-scale", 1.0);
+  r.text("expectations for %s %s: %s (warn under %.0f %%, fail under %.0f %%, scale %.2f)\n", arch.c_str(), name.c_str(),
+         e.known ? e.label.c_str() : "none: correctness is graded, performance only reported", 100 * e.warn_ratio, 100 * e.fail_ratio, e.scale);
+  std::string tj = "{";
+  bool first = true;
+  for (auto& kv : e.v) {
+    const double v = e.want(kv.first);
+    r.text("  %-32s %10.4g\n", kv.first.c_str(), v);
+    tj += std::string(first ? "" : ",") + "\"" + kv.first + "\":" + jnum(v);
+    first = false;
+  }
+  r.member("expect", "{\"arch\":" + jstr(arch) + ",\"known\":" + (e.known ? "true" : "false") + ",\"warn_ratio\":" + jnum(e.warn_ratio) +
+                         ",\"fail_ratio\":" + jnum(e.fail_ratio) + ",\"scale\":" + jnum(e.scale) + ",\"table\":" + tj + "}}");
+  if (a.has("--check")) {
+    diag_expect::Expect m;
+    if (!diag_expect::apply_overrides(a.str("--check"), &m, &bad)) {
+      fprintf(stderr, "--check: cannot read '%s'\n", bad.c_str());
+      return 2;
+    }
+    std::string cj = "{";
+    first = true;
+    for (auto& kv : m.v) {
+      const uint32_t system = kv.first.rfind("hbm.", 0) == 0 || kv.first.rfind("memtest.", 0) == 0 ? GM_HEALTH_WATCH_MEM
+                              : kv.first.rfind("soak.", 0) == 0                                    ? GM_HEALTH_WATCH_POWER
+                                                                                                    : GM_HEALTH_WATCH_COMPUTE;
+      const std::string test = kv.first.substr(0, kv.first.find('.'));
+      const int h = r.grade(test, system, kv.first, kv.second, e.want(kv.first), e, "");
+      r.verdict_pass(test, system, kv.second, "at its expected rate");
+      r.text("  check %-26s %10.4g -> %s\n", kv.first.c_str(), kv.second, diag_expect::health_name(h));
+      cj += std::string(first ? "" : ",") + "\"" + kv.first + "\":" + std::to_string(h);
+      first = false;
+    }
+    r.member("check", cj + "}");
+  }
+  return 0;
+}
+
+int cmd_run(const Args& a, Report& r, const std::vector<int>& gpus, MfmaWatch* mfma) {
   const int level = (int)a.num("-r", 1);
   if (level < 1 || level > 3) {
     fprintf(stderr, "-r takes 1, 2 or 3\n");
@@ -871,42 +1320,57 @@ int cmd_run(const Args& a, Report& r) {
   int rc;
   if ((rc = cmd_info(sub, r))) return rc;
   // level 1 (quick, seconds): short stream + 1 GiB memtest.  level 2 adds the matrix pipes and a 5 s
-  // GEMM stress.  level 3 sweeps 90 % of HBM, soaks 60 s and exercises the fabric.
+  // GEMM stress.  level 3 sweeps 90 % of HBM, soaks 60 s and exercises the fabric (once, over the GPUs of the run).
+  // With several GPUs every step runs on all of them at the same time.
   sub.kv["--bytes"] = level == 1 ? "1G" : "4G";
   sub.kv["--iters"] = level == 1 ? "5" : "20";
-  if ((rc = cmd_hbm(sub, r))) return rc;
+  if ((rc = run_on(sub, r, gpus, [](const Args& x, Report& y, int g) { return cmd_hbm(x, y, g); }))) return rc;
   if (level < 3) sub.kv["--bytes"] = level == 1 ? "1G" : "16G";
   else sub.kv.erase("--bytes");
-  if ((rc = cmd_memtest(sub, r))) return rc;
+  if ((rc = run_on(sub, r, gpus, [](const Args& x, Report& y, int g) { return cmd_memtest(x, y, g); }))) return rc;
   if (level >= 2) {
     sub.kv["--seconds"] = "1";
-    if ((rc = cmd_mfma(sub, r))) return rc;
-    sub.kv["--seconds"] = level == 2 ? "5" : "60";
+    if ((rc = run_on(sub, r, gpus, [](const Args& x, Report& y, int g) { return cmd_mfma(x, y, g); }))) return rc;
+    sub.kv["--seconds"] = a.has("--seconds") ? a.str("--seconds") : level == 2 ? "5" : "60";
     sub.kv.erase("--dtype");
-    if ((rc = cmd_gemm(sub, r))) return rc;
+    if ((rc = run_on(sub, r, gpus, [mfma](const Args& x, Report& y, int g) { return cmd_gemm(x, y, g, mfma); }))) return rc;
   }
-  if (level >= 3) {
+  compare_gpus(a, r);
+  if (level >= 3 && !a.has("--no-fabric")) {
     sub.kv.erase("--bytes");
     sub.kv.erase("--iters");
+    sub.kv.erase("--seconds");
     sub.kv["--scaling"] = "1";
+    // the fabric tests are about the GPUs of this run: all of them for a node run, the visible ones for one GPU
+    if (gpus.size() > 1) {
+      std::string list;
+      for (size_t i = 0; i < gpus.size(); i++) list += (i ? "," : "") + std::to_string(gpus[i]);
+      sub.kv["--gpus"] = list;
+    } else sub.kv.erase("--gpus");
     if ((rc = cmd_rccl(sub, r))) return rc;
-    if (gmd_device_count() > 1 && (rc = cmd_links(sub, r))) return rc;
+    if ((gpus.size() > 1 || gmd_device_count() > 1) && (rc = cmd_links(sub, r))) return rc;
   }
   return 0;
 }
 
 void usage() {
   fprintf(stderr,
-          "usage: gpumon-diag <info|hbm|memtest|mfma|gemm|rccl|links|run> [options] [--json] [--publish FILE]\n"
+          "usage: gpumon-diag <info|expect|hbm|memtest|mfma|gemm|rccl|links|run> [options] [--json] [--publish FILE]\n"
           "  --publish FILE leaves the JSON report where `gpumon-exporter --diag-results` picks it up\n"
-          "  hbm     [-g GPU] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
-          "  memtest [-g GPU] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N]\n"
-          "  mfma    [-g GPU] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
-          "  gemm    [-g GPU] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--min-tflops X] [--no-telemetry] [--mfma-counters]\n"
+          "  hbm     [-g GPU | --gpus LIST|all] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
+          "  memtest [-g GPU | --gpus LIST|all] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N]\n"
+          "  mfma    [-g GPU | --gpus LIST|all] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
+          "  gemm    [-g GPU | --gpus LIST|all] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--check-every N] [--min-tflops X]\n"
+          "          [--no-telemetry] [--mfma-counters]\n"
           "  rccl    [--gpus LIST] [--ops LIST] [--min-bytes N] [--max-bytes N] [--factor N] [--iters N] [--scaling] [--no-verify] [--min-busbw GBPS]\n"
-          "  links   [--gpus LIST] [--bytes N] [--iters N] [--modes uni,bidi,all] [--floor-gbps X] [--warn-ratio R] [--fail-ratio R]\n"
-          "          peer-store bandwidth of every xGMI link, graded against a floor and against the other links\n"
-          "  run     -r 1|2|3 [-g GPU]\n"
+          "  links   [--gpus LIST] [--bytes N] [--iters N] [--modes uni,bidi,all] [--direction push|pull|both] [--link-gbps X] [--floor-gbps X]\n"
+          "          [--warn-ratio R] [--fail-ratio R]\n"
+          "          peer-copy bandwidth of every xGMI link (remote stores and remote loads), read into findings per GPU, link and peer\n"
+          "  run     -r 1|2|3 [-g GPU | --gpus LIST|all] [--no-fabric]\n"
+          "  expect  [--arch ARCH] [--name PRODUCT] [--check KEY=VALUE,..]   the table a GPU is held against; grades given measurements\n"
+          "grading: throughputs against the expectation table of the GPU model (PASS, WARN under 90 %%, FAIL under 75 %%);\n"
+          "         [--expect key=value,..] [--expect-scale F] [--no-expect]; with --gpus also each GPU against the median of the\n"
+          "         others [--outlier-warn 0.95] [--outlier-fail 0.90]\n"
           "every command: [--json] [--publish FILE] [--submit ENGINE_ADDRESS [--submit-unix]]\n");
 }
 
@@ -926,26 +1390,33 @@ bool submit_verdicts(const Args& a, const Report& r) {
     fprintf(stderr, "error: cannot reach the host engine at %s: %s\n", addr.c_str(), gm_strerror(st));
     return false;
   }
-  // HIP device index -> the engine's index of the same card
-  auto engine_index = [](uint32_t hip) {
+  // HIP device index -> the engine's index of the same card; -1 when the engine does not have it
+  auto engine_index = [](int hip) {
     uint32_t n = 0;
-    gmd_device_info_t d;
-    if (gmd_device_info((int)hip, &d) == GMD_OK && gm_device_count(&n) == GM_ST_OK)
+    const std::string bdf = bdf_of_hip(hip);
+    if (!bdf.empty() && gm_device_count(&n) == GM_ST_OK)
       for (uint32_t i = 0; i < n; i++) {
         gm_device_attributes_t at;
         memset(&at, 0, sizeof at);
         at.version = GM_DEVICE_ATTRIBUTES_VERSION;
-        if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, d.pci_bdf) == 0) return i;
+        if (gm_device_attributes(i, &at) == GM_ST_OK && strcasecmp(at.pci_bdf, bdf.c_str()) == 0) return (int)i;
       }
-    return hip;
+    return -1;
   };
-  const uint32_t gpu = engine_index((uint32_t)a.num("-g", 0));
   bool ok = true;
-  for (auto& v : r.verdicts) {
+  const Report all = r.all_verdicts();
+  for (auto& v : all.verdicts) {
+    const int hip = v.gpu >= 0 ? v.gpu : r.gpu;
+    const int idx = hip >= 0 ? engine_index(hip) : -1;
+    if (idx < 0) {
+      fprintf(stderr, "warning: the %s verdict is about HIP device %d (%s), which the host engine does not list; not submitted\n", v.test.c_str(), hip,
+              hip >= 0 ? bdf_of_hip(hip).c_str() : "node");
+      continue;
+    }
     gm_diag_result_t dr;
     memset(&dr, 0, sizeof dr);
     dr.version = GM_DIAG_RESULT_VERSION;
-    dr.gpu = v.gpu >= 0 ? engine_index((uint32_t)v.gpu) : gpu;
+    dr.gpu = (uint32_t)idx;
     snprintf(dr.test, sizeof dr.test, "%s", v.test.c_str());
     dr.system = v.system;
     dr.health = v.health;
@@ -976,21 +1447,42 @@ int main(int argc, char** argv) {
   }
   Report r;
   r.json = a.has("--json");
+  // The matrix-pipe counter probe is a child process and must exist before this process touches the device.
+  MfmaWatch mfma;
+  const bool wants_mfma = a.has("--mfma-counters") && (cmd == "gemm" || cmd == "run");
+  const bool have_mfma = wants_mfma && mfma.start();
+  if (wants_mfma && !have_mfma) fprintf(stderr, "note: gpumon-prof-probe not found next to this binary; no matrix-pipe counters\n");
+  MfmaWatch* mw = have_mfma ? &mfma : nullptr;
   int rc;
+  const bool per_gpu = cmd == "hbm" || cmd == "memtest" || cmd == "mfma" || cmd == "gemm" || cmd == "run";
+  std::vector<int> gpus;
+  if (per_gpu) {
+    gpus = target_gpus(a);
+    if (gpus.empty()) {
+      fprintf(stderr, "error: no GPU to test: %s\n", gmd_last_error());
+      return 2;
+    }
+  }
   if (cmd == "info") rc = cmd_info(a, r);
-  else if (cmd == "hbm") rc = cmd_hbm(a, r);
-  else if (cmd == "memtest") rc = cmd_memtest(a, r);
-  else if (cmd == "mfma") rc = cmd_mfma(a, r);
-  else if (cmd == "gemm") rc = cmd_gemm(a, r);
+  else if (cmd == "expect") rc = cmd_expect(a, r);
+  else if (cmd == "hbm") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_hbm(x, y, g); });
+  else if (cmd == "memtest") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_memtest(x, y, g); });
+  else if (cmd == "mfma") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_mfma(x, y, g); });
+  else if (cmd == "gemm") rc = run_on(a, r, gpus, [mw](const Args& x, Report& y, int g) { return cmd_gemm(x, y, g, mw); });
   else if (cmd == "rccl") rc = cmd_rccl(a, r);
   else if (cmd == "links" || cmd == "p2p") rc = cmd_links(a, r);
-  else if (cmd == "run") rc = cmd_run(a, r);
+  else if (cmd == "run") rc = cmd_run(a, r, gpus, mw);
   else {
     usage();
     return 2;
   }
   if (rc) return rc;
-  rc = r.finish((int)a.num("-g", 0), a.str("--publish"));
+  if (per_gpu && cmd != "run") compare_gpus(a, r);
+  if (have_mfma) {
+    mfma.stop();
+    for (int g : gpus) r.member(gpus.size() > 1 ? "mfma_active_gpu" + std::to_string(g) : "mfma_active", mfma.fold(r, bdf_of_hip(g).c_str()));
+  }
+  rc = r.finish(a.str("--publish"), bdf_of_hip);
   if (rc != 2 && a.has("--submit") && !submit_verdicts(a, r)) return 2;
   return rc;
 }

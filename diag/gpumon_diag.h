@@ -153,6 +153,15 @@ GMD_API int gmd_mfma_peak(int device, int dtype, double seconds, gmd_mfma_result
  * every later launch's output checksum with the first one's (silent-data-corruption check). */
 GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, int verify,
                             gmd_mfma_result_t* out);
+/* The same with every knob.  The soak keeps the GEMM stream free of anything but GEMMs: launches alternate between
+ * two C buffers and the checksum of a finished C runs on a second stream beside the next GEMM. */
+typedef struct {
+  int32_t device, dtype, m, n, k;
+  int32_t verify;       /* reference comparison of the first launch + checksums */
+  int32_t check_every;  /* checksum every Nth launch; <= 0: every launch */
+  double seconds;
+} gmd_gemm_stress_config_t;
+GMD_API int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* out);
 /* One GEMM on caller memory.  A: [M,K] row-major, B: [N,K] row-major (i.e. B^T), C: [M,N] row-major bf16.
  * GMD_DT_BF16: A, B bf16.  GMD_DT_FP8: A, B OCP e4m3, unscaled (mfma_f32_16x16x128_f8f6f4, twice the rate of
  * mfma_f32_16x16x32_fp8_fp8, which schedules 0, 1, 3, 4, 5 and 7 run).
@@ -227,23 +236,31 @@ GMD_API double gmd_busbw_factor(int op, int ndev);
 /* *n: capacity of out on entry, points written on return. */
 GMD_API int gmd_rccl_sweep(const gmd_rccl_config_t* cfg, gmd_rccl_point_t* out, int* n);
 
-/* Link test: a copy kernel on the source GPU stores straight into the peer's memory (16 bytes per lane,
- * streaming stores), timed with HIP events on the source's stream, so the figure is the link's and not the
- * copy engines'.  Three traffic patterns over the same buffers:
- *   UNI   one ordered pair at a time              -> what one direction of one link carries
- *   BIDI  both directions of a pair at once       -> whether the link holds its rate full duplex
- *   ALL   every GPU writes to every peer at once  -> whether the links of a GPU are independent
- * gbps[i*ndev+j] is the rate devices[i] -> devices[j] under that pattern (1e9 bytes/s), 0 on the diagonal,
- * -1 without peer access.  With `verify`, bad[i*ndev+j] counts the 16-byte words that arrived different from
- * what was sent (bad may be NULL).  One GPU: the 1x1 matrix {0}, GMD_OK. */
+/* Link test: the compute units of one GPU (the initiator) copy between their own memory and a peer's, 16 bytes
+ * per lane with streaming accesses, so the figure is the link's and not the copy engines'.  Push (default): local
+ * loads, stores into the peer's memory.  Pull: loads from the peer's memory, local stores (what all-gather-by-read
+ * and P2P reads do).  Three traffic patterns over the same buffers:
+ *   UNI   one ordered pair at a time                 -> what one direction of one link carries
+ *   BIDI  both directions of a pair at once          -> whether the link holds its rate full duplex
+ *   ALL   every GPU works on every peer at once      -> whether the links of a GPU are independent
+ * Every GPU runs ONE launch per pattern step that serves all of its peers of that step (workgroup sets per peer), so
+ * ALL keeps seven links busy from one hardware queue; each pair is timed inside that launch by the earliest entry
+ * and latest exit of its own workgroups on the GPU's constant-rate real-time counter.
+ * gbps[i*ndev+j] is the rate at which devices[i] wrote to (push) or read from (pull) devices[j] under that pattern
+ * (1e9 bytes/s), 0 on the diagonal, -1 without peer access.  With `verify`, bad[i*ndev+j] counts the 16-byte words
+ * that arrived different from what was sent (bad may be NULL).  One GPU: the 1x1 matrix {0}, GMD_OK. */
+#define GMD_LINK_MAX_PEERS 63
 typedef enum { GMD_LINK_UNI = 0, GMD_LINK_BIDI = 1, GMD_LINK_ALL = 2 } gmd_link_mode_t;
 typedef struct {
   int32_t ndev;        /* 0 = all visible GPUs */
   const int* devices;  /* NULL = 0..ndev-1 */
   uint64_t bytes;      /* per transfer; default 256 MiB */
-  int32_t iters;       /* timed transfers per pair; default 5 */
+  int32_t iters;       /* timed passes over the buffer per pair; default 5 */
   int32_t verify;      /* 1 = check the data at the destination after the timed transfers */
-  int32_t workgroups;  /* copy kernel grid per peer; default 64 (256 lanes each) */
+  int32_t workgroups;  /* workgroups per peer (256 lanes each); default 64 */
+  int32_t pull;        /* 1 = remote loads, local stores */
+  double* per_gpu_gbps; /* ALL only, may be NULL: ndev entries, bytes the GPU's one launch moved over the time between
+                           the HIP events around it (all peers together; an independent clock for the stamps) */
 } gmd_link_config_t;
 GMD_API int gmd_link_test(const gmd_link_config_t* cfg, int mode, double* gbps, uint64_t* bad);
 
@@ -252,7 +269,20 @@ GMD_API int gmd_link_test(const gmd_link_config_t* cfg, int mode, double* gbps, 
  * touched guard word past the end. */
 GMD_API int gmd_link_selftest(int device, uint64_t bytes, int workgroups, double* gbps, uint64_t* bad);
 
-/* Grading of a link matrix, host arithmetic only (no GPU needed).  A pair fails when it has no peer access,
+/* The fused all-peers launch inside one GPU: `npeers` local sources and destinations stand in for the peers.  gbps and
+ * bad take npeers entries.  The result relates the two clocks: every peer's stamp window must lie inside the time
+ * between the HIP events around the launch. */
+typedef struct {
+  int32_t npeers;
+  double launch_ms;                    /* HIP events around the timed launch */
+  double window_ms_min, window_ms_max; /* shortest and longest per-peer stamp window */
+  double launch_gbps;                  /* all peers' bytes over launch_ms */
+  double tick_hz;                      /* rate of the real-time counter the stamps are in */
+} gmd_link_fan_result_t;
+GMD_API int gmd_link_fan_selftest(int device, int npeers, uint64_t bytes, int workgroups, int iters, double* gbps, uint64_t* bad,
+                                  gmd_link_fan_result_t* result);
+
+/* Grading of one link matrix, host arithmetic only (no GPU needed).  A pair fails when it has no peer access,
  * delivered corrupt data, runs below the absolute floor, or below fail_ratio of the median of the other pairs;
  * it warns below warn_ratio of that median.  The sibling median needs at least two other measured pairs;
  * with fewer only the floor applies.  *n: capacity of out on entry, verdicts written on return (one per ordered
@@ -271,6 +301,68 @@ typedef struct {
 } gmd_link_verdict_t;
 GMD_API int gmd_link_grade(int ndev, const double* gbps, const uint64_t* bad, const gmd_link_rule_t* rule,
                            gmd_link_verdict_t* out, int* n);
+
+/* What a healthy node is expected to deliver, derived from the advertised rate of one direction of one link (the
+ * engine's link table has it; 76.8 GB/s on MI355X, whose 153.6 GB/s per link counts both directions).  The
+ * deratings say which fraction of that rate a copy kernel is expected to reach per direction under each traffic
+ * pattern; a measurement warns below warn_ratio and fails below fail_ratio of its expectation.  Members <= 0 take
+ * the defaults given here. */
+typedef struct {
+  double link_gbps;         /* one direction of one link, 1e9 bytes/s; default 76.8 */
+  double derate_uni;        /* one pair at a time; default 0.70 */
+  double derate_bidi;       /* per direction with both busy; default 0.65 */
+  double derate_all;        /* per link with every link of every GPU busy; default 0.60 */
+  double pull_factor;       /* remote loads against remote stores; default 0.80 */
+  double derate_collective; /* collectives that can use all n-1 links of a GPU, per link; default 0.50 */
+  double warn_ratio;        /* default 0.90 */
+  double fail_ratio;        /* default 0.75 */
+  double scale;             /* multiplies every expectation (a stricter or laxer site, tests); default 1 */
+  int32_t pull;             /* the matrices were measured with remote loads */
+} gmd_link_expect_t;
+GMD_API void gmd_link_expect_defaults(gmd_link_expect_t* e);
+/* Expected rate per direction of one link under a pattern, times `peers` (>= 1). */
+GMD_API double gmd_link_expected_gbps(const gmd_link_expect_t* e, int mode, int peers);
+/* Expected peak bus bandwidth of a collective on ndev GPUs (0 for one GPU: nothing crosses a link).  All-reduce
+ * and broadcast: one direction of one link at the one-pair derating (a ring is bound by one link per hop, and
+ * nothing the library builds on the mesh may be slower than that).  All-gather, reduce-scatter, all-to-all: the
+ * n-1 links of a GPU together at the collective derating. */
+GMD_API double gmd_rccl_expected_busbw(const gmd_link_expect_t* e, int op, int ndev);
+/* 0 / 10 / 20 for a value against its expectation (0 when there is no expectation). */
+GMD_API int gmd_grade_against(double value, double expected, double warn_ratio, double fail_ratio);
+/* Each value against the median of the others (GPUs of one node under the same load): warn below warn_ratio
+ * (default 0.95), fail below fail_ratio (default 0.90).  health and others_median (may be NULL) take n entries;
+ * one value alone passes.  Returns the worst health. */
+GMD_API int gmd_outlier_grade(int n, const double* values, double warn_ratio, double fail_ratio, int32_t* health,
+                              double* others_median);
+
+/* The three matrices of a link test read together (host arithmetic only).  A finding names what is wrong and where:
+ *   no_access, corrupt_data, slow_link (one pair at a time: against the expectation and against the other links),
+ *   half_duplex (a direction that loses its rate when the other is busy), low_egress / low_ingress (a GPU that
+ *   moves less than the others, or than expected, as initiator / as peer with every link busy; dst / src = -1),
+ *   slow_under_load (a pair that falls behind its GPU's other links only with every link busy).
+ * A pair with a finding is left out of the busier patterns' statistics, so one fault gives one finding.  bidi and
+ * all may be NULL (pattern not run); bad counts corrupt words per pair over all patterns (may be NULL).
+ * *n: capacity of out on entry, findings written on return.  Returns the worst health, or an error. */
+typedef enum {
+  GMD_LINK_NO_ACCESS = 0,
+  GMD_LINK_CORRUPT = 1,
+  GMD_LINK_SLOW = 2,
+  GMD_LINK_HALF_DUPLEX = 3,
+  GMD_LINK_SLOW_UNDER_LOAD = 4,
+  GMD_LINK_LOW_EGRESS = 5,
+  GMD_LINK_LOW_INGRESS = 6,
+  GMD_LINK_FINDING_KINDS = 7
+} gmd_link_finding_kind_t;
+typedef struct {
+  int32_t kind, mode;  /* gmd_link_finding_kind_t, gmd_link_mode_t */
+  int32_t src, dst;    /* initiator and peer positions in the device list; -1 = the whole GPU on the other side */
+  int32_t health;      /* 10 warn, 20 fail */
+  double gbps, expected_gbps;
+  char message[192];
+} gmd_link_finding_t;
+GMD_API const char* gmd_link_finding_name(int kind);
+GMD_API int gmd_link_diagnose(int ndev, const double* uni, const double* bidi, const double* all, const uint64_t* bad,
+                              const gmd_link_expect_t* expect, gmd_link_finding_t* out, int* n);
 
 /* Pairwise copy bandwidth over the GPU fabric with peer access (hipMemcpyPeerAsync):
  * gbps[i*ndev+j] = devices[i] -> devices[j], 0 on the diagonal, -1 where peer access

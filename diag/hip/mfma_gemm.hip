@@ -2021,8 +2021,18 @@ int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int rows, int
 }
 
 int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, int verify, gmd_mfma_result_t* out) {
-  if (!out) return GMD_ERR_BADPARAM;
+  gmd_gemm_stress_config_t cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.device = device, cfg.dtype = dtype, cfg.m = m, cfg.n = n, cfg.k = k, cfg.seconds = seconds, cfg.verify = verify;
+  return gmd_gemm_stress_run(&cfg, out);
+}
+
+int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* out) {
+  if (!out || !cfg) return GMD_ERR_BADPARAM;
   memset(out, 0, sizeof *out);
+  const int device = cfg->device, dtype = cfg->dtype, m = cfg->m, n = cfg->n, k = cfg->k, verify = cfg->verify;
+  const double seconds = cfg->seconds;
+  const int check_every = cfg->check_every > 0 ? cfg->check_every : 1;
   const bool fp8 = dtype == GMD_DT_FP8 || dtype == GMD_DT_MXFP8;
   const bool mx = dtype == GMD_DT_MXFP8;
   if (dtype != GMD_DT_BF16 && !fp8) return GMD_ERR_BADPARAM;
@@ -2032,14 +2042,14 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
   }
   GMD_HIP(hipSetDevice(device));
   const size_t esz = fp8 ? 1 : 2;
-  gmd::DeviceBuffer a, b, c, sums, sa_nat, sb_nat, sa_pk, sb_pk, refs;
+  gmd::DeviceBuffer a, b, c, c2, sums, sa_nat, sb_nat, sa_pk, sb_pk, refs;
   int rc;
   // Checksums land in a window of slots that is drained to the host (compared, cleared) whenever it is
   // full, so the soak runs for as long as it is asked to.
   const int kWindow = 1 << 13;
   const int kSamples = 4096;
   if ((rc = a.alloc((size_t)m * k * esz)) || (rc = b.alloc((size_t)n * k * esz)) || (rc = c.alloc((size_t)m * n * 2)) ||
-      (rc = sums.alloc(sizeof(unsigned long long) * kWindow)) || (rc = refs.alloc(sizeof(float) * 2 * kSamples)))
+      (rc = c2.alloc((size_t)m * n * 2)) || (rc = sums.alloc(sizeof(unsigned long long) * kWindow)) || (rc = refs.alloc(sizeof(float) * 2 * kSamples)))
     return rc;
   if (fp8) {
     fill_fp8_kernel<<<2048, 256>>>((uint8_t*)a.p, (uint64_t)m * k, 1);
@@ -2058,6 +2068,7 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
   }
   auto launch = [&]() { return gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, c.p, m, n, k, nullptr); };
   GMD_HIP(hipMemset(sums.p, 0, sizeof(unsigned long long) * kWindow));
+  GMD_HIP(hipMemset(c2.p, 0, (size_t)m * n * 2));
   GMD_HIP(hipGetLastError());
   if ((rc = launch())) return rc;  // warm-up; also the launch that is checked against the reference
   GMD_HIP(hipDeviceSynchronize());
@@ -2088,18 +2099,44 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
     }
   }
 
+  // The soak proper.  The matrix pipes are to stay saturated for the whole run, so nothing but GEMMs goes into
+  // the GEMM stream: launches alternate between two C buffers, and the checksum of a finished C runs on a second
+  // stream next to the following GEMM (it reads 2 bytes per output element; the GEMM after that waits for it before
+  // it overwrites the buffer).  The host stays three batches ahead of the device and never drains the queue except
+  // to empty the checksum window.
   const uint64_t n16 = (uint64_t)m * n * 2 / 16;
-  hipEvent_t e0, e1;
-  GMD_HIP(hipEventCreate(&e0));
-  GMD_HIP(hipEventCreate(&e1));
+  constexpr int kMarkRing = 4;
+  struct Rig {
+    hipStream_t gemm = nullptr, check = nullptr;
+    hipEvent_t written[2] = {nullptr, nullptr}, checked[2] = {nullptr, nullptr};
+    hipEvent_t mark[kMarkRing + 1] = {};
+    ~Rig() {
+      for (hipEvent_t e : written) if (e) (void)hipEventDestroy(e);
+      for (hipEvent_t e : checked) if (e) (void)hipEventDestroy(e);
+      for (hipEvent_t e : mark) if (e) (void)hipEventDestroy(e);
+      if (gemm) (void)hipStreamDestroy(gemm);
+      if (check) (void)hipStreamDestroy(check);
+    }
+  } rig;
+  GMD_HIP(hipStreamCreateWithFlags(&rig.gemm, hipStreamNonBlocking));
+  GMD_HIP(hipStreamCreateWithFlags(&rig.check, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    GMD_HIP(hipEventCreateWithFlags(&rig.written[i], hipEventDisableTiming));
+    GMD_HIP(hipEventCreateWithFlags(&rig.checked[i], hipEventDisableTiming));
+  }
+  for (auto& e : rig.mark) GMD_HIP(hipEventCreate(&e));
+  void* cbuf[2] = {c.p, c2.p};
+  bool pending[2] = {false, false};
   const double flops = 2.0 * m * n * (double)k;
-  double t_start = now_s(), gpu_s = 0, best_ms = 1e30;
-  uint64_t launches = 0, in_window = 0;
+  const double t_start = now_s();
+  double gpu_s = 0, best_ms = 1e30;
+  uint64_t launches = 0, in_window = 0, batches = 0;
   unsigned long long ref_sum = 0;
   bool have_ref = false;
   std::vector<unsigned long long> h(kWindow);
-  auto drain = [&]() -> int {  // device idle: compare the window against the first launch's checksum, clear it
+  auto drain = [&]() -> int {  // both streams idle: compare the window against the first checksum, clear it
     if (!verify || !in_window) return GMD_OK;
+    GMD_HIP(hipStreamSynchronize(rig.check));
     GMD_HIP(hipMemcpy(h.data(), sums.p, in_window * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (!have_ref) ref_sum = h[0], have_ref = true;
     for (uint64_t i = 0; i < in_window; i++)
@@ -2108,28 +2145,61 @@ int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, 
     in_window = 0;
     return GMD_OK;
   };
-  for (;;) {
-    // Batches of launches between host syncs keep the queue full.
-    const int batch = 8;
-    GMD_HIP(hipEventRecord(e0, 0));
-    for (int i = 0; i < batch; i++) {
-      if ((rc = launch())) return rc;
-      if (verify) checksum_kernel<<<2048, 256>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + in_window + i);
-    }
-    GMD_HIP(hipEventRecord(e1, 0));
+  const int batch = 8;
+  // mark[b % (kRing + 1)] closes batch b; batch b's time is the distance between marks b-1 and b.
+  auto settle = [&](uint64_t b) -> int {
+    hipEvent_t e1 = rig.mark[b % (kMarkRing + 1)], e0 = rig.mark[(b + kMarkRing) % (kMarkRing + 1)];
     GMD_HIP(hipEventSynchronize(e1));
     float ms = 0;
     GMD_HIP(hipEventElapsedTime(&ms, e0, e1));
-    launches += batch;
-    in_window += batch;
     gpu_s += ms * 1e-3;
     best_ms = std::min(best_ms, (double)ms / batch);
-    if (in_window + batch > (uint64_t)kWindow && (rc = drain())) return rc;
+    return GMD_OK;
+  };
+  GMD_HIP(hipEventRecord(rig.mark[0], rig.gemm));
+  uint64_t settled = 0;  // batches 1..settled are accounted for
+  for (;;) {
+    for (int i = 0; i < batch; i++, launches++) {
+      const int w = (int)(launches & 1);
+      if (pending[w]) {
+        GMD_HIP(hipStreamWaitEvent(rig.gemm, rig.checked[w], 0));
+        pending[w] = false;
+      }
+      if ((rc = gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, cbuf[w], m, n, k, rig.gemm))) return rc;
+      if (verify && launches % check_every == 0) {
+        GMD_HIP(hipEventRecord(rig.written[w], rig.gemm));
+        GMD_HIP(hipStreamWaitEvent(rig.check, rig.written[w], 0));
+        checksum_kernel<<<2048, 256, 0, rig.check>>>((const uint4*)cbuf[w], n16, (unsigned long long*)sums.p + in_window);
+        GMD_HIP(hipEventRecord(rig.checked[w], rig.check));
+        pending[w] = true;
+        in_window++;
+      }
+    }
+    batches++;
+    GMD_HIP(hipEventRecord(rig.mark[batches % (kMarkRing + 1)], rig.gemm));
+    // at most kRing - 1 batches in flight: the slot that the next mark takes has been read by then
+    while (batches - settled >= (uint64_t)kMarkRing - 1) {
+      if ((rc = settle(settled + 1))) return rc;
+      settled++;
+    }
+    if (in_window + batch > (uint64_t)kWindow) {
+      // Emptying the window idles the device once per kWindow checksums; the idle time is not GEMM time.
+      while (settled < batches) {
+        if ((rc = settle(settled + 1))) return rc;
+        settled++;
+      }
+      if ((rc = drain())) return rc;
+      GMD_HIP(hipEventRecord(rig.mark[batches % (kMarkRing + 1)], rig.gemm));
+    }
     if (now_s() - t_start >= seconds) break;
   }
+  while (settled < batches) {
+    if ((rc = settle(settled + 1))) return rc;
+    settled++;
+  }
+  GMD_HIP(hipStreamSynchronize(rig.gemm));
+  GMD_HIP(hipStreamSynchronize(rig.check));
   GMD_HIP(hipGetLastError());
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   out->launches = launches;
   out->seconds = gpu_s;
   out->tflops = flops * (double)launches / gpu_s / 1e12;

@@ -107,6 +107,7 @@ __global__ void check_kernel(const float* p, uint64_t n, int op, int rank, int w
 struct Dev {
   int id = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
   float* send = nullptr;
   float* recv = nullptr;
   unsigned long long* bad = nullptr;
@@ -122,10 +123,35 @@ struct Sweep {
     for (auto& d : devs) {
       (void)hipSetDevice(d.id);
       if (d.stream) (void)hipStreamDestroy(d.stream);
+      if (d.t0) (void)hipEventDestroy(d.t0);
+      if (d.t1) (void)hipEventDestroy(d.t1);
       if (d.send) (void)hipFree(d.send);
       if (d.recv) (void)hipFree(d.recv);
       if (d.bad) (void)hipFree(d.bad);
     }
+  }
+
+  // Device-side clock of a timed run: an event on every GPU's stream before and after, the slowest GPU counts.
+  // (A host clock around the calls would add the cost of enqueueing to every row.  Rows of less than about
+  // 1 MiB are still bound by launch latency, not by the links: `iters` grouped launches take what the host
+  // needs to issue them.)
+  int mark(bool begin) {
+    for (auto& d : devs) {
+      GMD_HIP(hipSetDevice(d.id));
+      GMD_HIP(hipEventRecord(begin ? d.t0 : d.t1, d.stream));
+    }
+    return GMD_OK;
+  }
+  int elapsed_s(double* s) {
+    *s = 0;
+    for (auto& d : devs) {
+      GMD_HIP(hipSetDevice(d.id));
+      GMD_HIP(hipEventSynchronize(d.t1));
+      float ms = 0;
+      GMD_HIP(hipEventElapsedTime(&ms, d.t0, d.t1));
+      *s = std::max(*s, (double)ms * 1e-3);
+    }
+    return GMD_OK;
   }
 
   int sync_all() {
@@ -260,6 +286,8 @@ int gmd_rccl_sweep(const gmd_rccl_config_t* cfg_in, gmd_rccl_point_t* out, int* 
     d.id = ids[r];
     GMD_HIP(hipSetDevice(d.id));
     GMD_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    GMD_HIP(hipEventCreate(&d.t0));
+    GMD_HIP(hipEventCreate(&d.t1));
     GMD_HIP(hipMalloc((void**)&d.send, max_elems * 4));
     GMD_HIP(hipMalloc((void**)&d.recv, max_elems * 4));
     GMD_HIP(hipMalloc((void**)&d.bad, sizeof(unsigned long long)));
@@ -307,11 +335,12 @@ int gmd_rccl_sweep(const gmd_rccl_config_t* cfg_in, gmd_rccl_point_t* out, int* 
       for (int i = 0; i < cfg.warmup; i++)
         if ((rc = s.launch(op, n))) return rc;
       if ((rc = s.sync_all())) return rc;
-      const double t0 = now_s();
+      if ((rc = s.mark(true))) return rc;
       for (int i = 0; i < iters; i++)
         if ((rc = s.launch(op, n))) return rc;
-      if ((rc = s.sync_all())) return rc;
-      const double dt = (now_s() - t0) / iters;
+      double total = 0;
+      if ((rc = s.mark(false)) || (rc = s.elapsed_s(&total)) || (rc = s.sync_all())) return rc;
+      const double dt = std::max(total, 1e-9) / iters;
       p.iters = iters;
       p.time_us = dt * 1e6;
       p.algbw_gbps = p.bytes / dt / 1e9;
@@ -331,7 +360,20 @@ int gmd_p2p_matrix(int ndev, const int* devices, uint64_t bytes, int iters, doub
   if (!bytes) bytes = 256ull << 20;
   if (iters <= 0) iters = 5;
   std::vector<gmd::DeviceBuffer> src(w), dst(w);
-  std::vector<hipStream_t> streams(w, nullptr);
+  struct Streams {  // destroyed on every way out, each on its own device
+    std::vector<int> ids;
+    std::vector<hipStream_t> s;
+    ~Streams() {
+      for (size_t i = 0; i < s.size(); i++) {
+        if (!s[i]) continue;
+        (void)hipSetDevice(ids[i]);
+        (void)hipStreamDestroy(s[i]);
+      }
+    }
+  } owned;
+  owned.ids = ids;
+  owned.s.assign(w, nullptr);
+  std::vector<hipStream_t>& streams = owned.s;
   for (int i = 0; i < w; i++) {
     GMD_HIP(hipSetDevice(ids[i]));
     if ((rc = src[i].alloc(bytes)) || (rc = dst[i].alloc(bytes))) return rc;
@@ -365,10 +407,6 @@ int gmd_p2p_matrix(int ndev, const int* devices, uint64_t bytes, int iters, doub
       GMD_HIP(hipStreamSynchronize(streams[i]));
       cell = bytes * (double)iters / (now_s() - t0) / 1e9;
     }
-  }
-  for (int i = 0; i < w; i++) {
-    (void)hipSetDevice(ids[i]);
-    (void)hipStreamDestroy(streams[i]);
   }
   return GMD_OK;
 }

@@ -181,11 +181,21 @@ def mfma_peak(dtype="bf16", seconds=1.0, device=0):
     return _dict(r)
 
 
-def gemm_stress(dtype="bf16", m=8192, n=8192, k=8192, seconds=2.0, verify=True, device=0):
+class GemmStressConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("dtype", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+                ("verify", C.c_int32), ("check_every", C.c_int32), ("seconds", C.c_double)]
+
+
+def gemm_stress(dtype="bf16", m=8192, n=8192, k=8192, seconds=2.0, verify=True, device=0, check_every=1):
+    """GEMM soak: back-to-back launches alternating between two C buffers, the checksum of every `check_every`-th
+    result on a second stream next to the following GEMM, the first launch compared with an fp32 reference."""
+    L = _lib()
+    L.gmd_gemm_stress_run.argtypes = [C.POINTER(GemmStressConfig), C.POINTER(MfmaResult)]
+    cfg = GemmStressConfig(device, DTYPES[dtype], m, n, k, int(verify), check_every, seconds)
     r = MfmaResult()
-    rc = _lib().gmd_gemm_stress(device, DTYPES[dtype], m, n, k, seconds, int(verify), C.byref(r))
+    rc = L.gmd_gemm_stress_run(C.byref(cfg), C.byref(r))
     if rc:
-        raise DiagError(rc, f"gmd_gemm_stress({dtype})")
+        raise DiagError(rc, f"gmd_gemm_stress_run({dtype})")
     return _dict(r)
 
 
@@ -264,9 +274,13 @@ def p2p_matrix(devices=None, bytes=256 << 20, iters=5):
 LINK_MODES = {"uni": 0, "bidi": 1, "all": 2}
 
 
+LINK_MAX_PEERS = 63
+
+
 class LinkConfig(C.Structure):
     _fields_ = [("ndev", C.c_int32), ("devices", C.POINTER(C.c_int)), ("bytes", C.c_uint64), ("iters", C.c_int32),
-                ("verify", C.c_int32), ("workgroups", C.c_int32)]
+                ("verify", C.c_int32), ("workgroups", C.c_int32), ("pull", C.c_int32),
+                ("per_gpu_gbps", C.POINTER(C.c_double))]
 
 
 class LinkRule(C.Structure):
@@ -278,21 +292,44 @@ class LinkVerdict(C.Structure):
                 ("sibling_median_gbps", C.c_double), ("message", C.c_char * 160)]
 
 
-def link_test(mode="uni", devices=None, bytes=256 << 20, iters=5, verify=True, workgroups=0):
-    """Peer-store bandwidth matrix over the xGMI links (a copy kernel on the source GPU, HIP-event timed).
-    mode: "uni" one pair at a time, "bidi" both directions of a pair at once, "all" every GPU to every peer at
-    once.  Returns (gbps, bad): gbps[i][j] = devices[i] -> devices[j] in GB/s (-1 without peer access), bad[i][j] =
-    corrupt 16-byte words.  One GPU gives ([[0.0]], [[0]])."""
+class LinkFanResult(C.Structure):
+    _fields_ = [("npeers", C.c_int32), ("launch_ms", C.c_double), ("window_ms_min", C.c_double),
+                ("window_ms_max", C.c_double), ("launch_gbps", C.c_double), ("tick_hz", C.c_double)]
+
+
+class LinkExpect(C.Structure):
+    _fields_ = [("link_gbps", C.c_double), ("derate_uni", C.c_double), ("derate_bidi", C.c_double),
+                ("derate_all", C.c_double), ("pull_factor", C.c_double), ("derate_collective", C.c_double),
+                ("warn_ratio", C.c_double), ("fail_ratio", C.c_double), ("scale", C.c_double), ("pull", C.c_int32)]
+
+
+class LinkFinding(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("mode", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32),
+                ("health", C.c_int32), ("gbps", C.c_double), ("expected_gbps", C.c_double),
+                ("message", C.c_char * 192)]
+
+
+def link_test(mode="uni", devices=None, bytes=256 << 20, iters=5, verify=True, workgroups=0, pull=False,
+              with_per_gpu=False):
+    """Peer-copy bandwidth matrix over the xGMI links: a copy kernel on the initiating GPU, one launch per GPU that
+    serves all of its peers of the pattern step, each pair timed inside it by its own workgroups' stamps.
+    mode: "uni" one pair at a time, "bidi" both directions of a pair at once, "all" every GPU on every peer at
+    once.  pull=False: remote stores; pull=True: remote loads.  Returns (gbps, bad): gbps[i][j] = rate at which
+    devices[i] wrote to / read from devices[j] in GB/s (-1 without peer access), bad[i][j] = corrupt 16-byte words;
+    with_per_gpu adds the per-GPU totals by the HIP events around each launch ("all" only).  One GPU gives
+    ([[0.0]], [[0]])."""
     L = _lib()
     L.gmd_link_test.argtypes = [C.POINTER(LinkConfig), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     n = len(devices) if devices else device_count()
     arr = (C.c_int * n)(*devices) if devices else None
-    cfg = LinkConfig(n, arr, bytes, iters, 1 if verify else 0, workgroups)
+    per = (C.c_double * n)()
+    cfg = LinkConfig(n, arr, bytes, iters, 1 if verify else 0, workgroups, 1 if pull else 0, per)
     m, b = (C.c_double * (n * n))(), (C.c_uint64 * (n * n))()
     rc = L.gmd_link_test(C.byref(cfg), LINK_MODES[mode], m, b)
     if rc:
         raise DiagError(rc, f"gmd_link_test({mode})")
-    return [[m[i * n + j] for j in range(n)] for i in range(n)], [[b[i * n + j] for j in range(n)] for i in range(n)]
+    out = ([[m[i * n + j] for j in range(n)] for i in range(n)], [[b[i * n + j] for j in range(n)] for i in range(n)])
+    return out + (list(per),) if with_per_gpu else out
 
 
 def link_selftest(bytes=256 << 20, workgroups=0, device=0):
@@ -304,6 +341,94 @@ def link_selftest(bytes=256 << 20, workgroups=0, device=0):
     if rc:
         raise DiagError(rc, "gmd_link_selftest")
     return g.value, b.value
+
+
+def link_fan_selftest(npeers=7, bytes=64 << 20, workgroups=0, iters=5, device=0):
+    """The fused all-peers launch with `npeers` local destinations standing in for the peers: per-destination rates
+    from the in-kernel stamps, bad words per destination, and the relation of the stamp windows to the HIP-event
+    time of the launch.  Returns (gbps list, bad list, result dict)."""
+    L = _lib()
+    L.gmd_link_fan_selftest.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_uint64), C.POINTER(LinkFanResult)]
+    g, b, r = (C.c_double * npeers)(), (C.c_uint64 * npeers)(), LinkFanResult()
+    rc = L.gmd_link_fan_selftest(device, npeers, bytes, workgroups, iters, g, b, C.byref(r))
+    if rc:
+        raise DiagError(rc, "gmd_link_fan_selftest")
+    return list(g), list(b), _dict(r)
+
+
+def _expect(expect):
+    e = LinkExpect()
+    for k, v in (expect or {}).items():
+        setattr(e, k, v)
+    return e
+
+
+def link_expected_gbps(mode="uni", peers=1, **expect):
+    """Expected rate per direction of one link under a traffic pattern, times `peers` (see gmd_link_expect_t)."""
+    L = _lib()
+    L.gmd_link_expected_gbps.restype = C.c_double
+    L.gmd_link_expected_gbps.argtypes = [C.POINTER(LinkExpect), C.c_int, C.c_int]
+    return L.gmd_link_expected_gbps(C.byref(_expect(expect)), LINK_MODES[mode], peers)
+
+
+def rccl_expected_busbw(op, ndev, **expect):
+    """Expected peak bus bandwidth of a collective on ndev GPUs, from the link rate (0 for one GPU)."""
+    L = _lib()
+    L.gmd_rccl_expected_busbw.restype = C.c_double
+    L.gmd_rccl_expected_busbw.argtypes = [C.POINTER(LinkExpect), C.c_int, C.c_int]
+    return L.gmd_rccl_expected_busbw(C.byref(_expect(expect)), COLLECTIVES[op], ndev)
+
+
+def grade_against(value, expected, warn_ratio=0.90, fail_ratio=0.75):
+    L = _lib()
+    L.gmd_grade_against.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double]
+    return L.gmd_grade_against(value, expected, warn_ratio, fail_ratio)
+
+
+def outlier_grade(values, warn_ratio=0.0, fail_ratio=0.0):
+    """Each value against the median of the others: (worst, [health], [median of the others])."""
+    L = _lib()
+    L.gmd_outlier_grade.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_double)]
+    n = len(values)
+    v = (C.c_double * n)(*[float(x) for x in values])
+    h, m = (C.c_int32 * n)(), (C.c_double * n)()
+    rc = L.gmd_outlier_grade(n, v, warn_ratio, fail_ratio, h, m)
+    if rc < 0:
+        raise DiagError(rc, "gmd_outlier_grade")
+    return rc, list(h), list(m)
+
+
+def link_diagnose(uni, bidi=None, all_=None, bad=None, **expect):
+    """The link matrices of the three patterns read together (host arithmetic, no GPU): returns (worst_health,
+    [finding dict]); a finding has kind (no_access, corrupt_data, slow_link, half_duplex, slow_under_load, low_egress,
+    low_ingress), pattern, src, dst (-1 = the whole GPU on that side), health, gbps, expected_gbps, message."""
+    L = _lib()
+    L.gmd_link_diagnose.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_uint64), C.POINTER(LinkExpect), C.POINTER(LinkFinding),
+                                    C.POINTER(C.c_int)]
+    L.gmd_link_finding_name.restype = C.c_char_p
+    n = len(uni)
+
+    def flat(m, t):
+        return (t * (n * n))(*[x for row in m for x in row]) if m is not None else None
+
+    cap = 3 * n * n + 2 * n + 1
+    out = (LinkFinding * cap)()
+    cnt = C.c_int(cap)
+    rc = L.gmd_link_diagnose(n, flat(uni, C.c_double), flat(bidi, C.c_double), flat(all_, C.c_double),
+                             flat(bad, C.c_uint64), C.byref(_expect(expect)), out, C.byref(cnt))
+    if rc < 0:
+        raise DiagError(rc, "gmd_link_diagnose")
+    names = {v: k for k, v in LINK_MODES.items()}
+    res = []
+    for i in range(cnt.value):
+        d = _dict(out[i])
+        d["kind"] = L.gmd_link_finding_name(d["kind"]).decode()
+        d["pattern"] = names[d.pop("mode")]
+        res.append(d)
+    return rc, res
 
 
 def link_grade(gbps, bad=None, floor_gbps=0.0, warn_ratio=0.0, fail_ratio=0.0):
