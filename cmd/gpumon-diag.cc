@@ -714,16 +714,17 @@ struct Soak {
   }
   // The soak's verdicts (after summarize).  `seconds` = how long the GPU was under load.
   void judge(Report& r, const diag_expect::Expect& e, double seconds) {
-    if (!on || !e.known || seconds < 2) return;
+    if (!on) return;
     auto has = [&](const char* k) { return stats.count(k) && stats[k].n > 0; };
+    if (has("gfx_clock")) r.metrics["soak.gfx_clock_mhz"] = stats["gfx_clock"].avg();
+    if (has("power")) r.metrics["soak.power_w"] = stats["power"].avg();
+    if (!e.known || seconds < 2) return;
     if (has("gfx_clock")) {
       const double clk = stats["gfx_clock"].avg();
-      r.metrics["soak.gfx_clock_mhz"] = clk;
       r.grade("soak_clock", GM_HEALTH_WATCH_POWER, "shader clock held under load", clk, e.want("soak.gfx_clock_mhz"), e, "MHz");
       r.verdict_pass("soak_clock", GM_HEALTH_WATCH_POWER, clk, strprintf_local("held %.0f MHz under load", clk));
     }
     if (has("power")) {
-      r.metrics["soak.power_w"] = stats["power"].avg();
       if (std::isfinite(power_cap_w) && power_cap_w > 0) {
         // a healthy part under a matrix load comes close to its cap; one that cannot is held back by something else
         const double frac = stats["power"].hi / power_cap_w;
@@ -780,7 +781,7 @@ int cmd_gemm(const Args& a, Report& r, int gpu, MfmaWatch* mfma) {
     gmd_gemm_stress_config_t cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.device = gpu, cfg.dtype = dt, cfg.m = m, cfg.n = n, cfg.k = k, cfg.seconds = secs, cfg.verify = 1;
-    cfg.check_every = (int)a.num("--check-every", 1);
+    cfg.check_every = (int)a.num("--check-every", 0);
     gmd_mfma_result_t g;
     const double t_begin = MfmaWatch::now();
     int rc = gmd_gemm_stress_run(&cfg, &g);
@@ -1234,6 +1235,7 @@ void compare_gpus(const Args& a, Report& r) {
         r.subs[i].verdict("peer_compare", system, h[i], v[i],
                           strprintf_local("%s %.4g is %.1f %% of the other GPUs' median %.4g under the same load", key.c_str(), v[i], 100 * v[i] / med[i], med[i]));
     }
+    cj += "]";
     r.text("\n");
   }
   for (auto& s : r.subs) {

@@ -364,7 +364,7 @@ def test_gemm_stress_and_pipe_peak(diag):
     g = diag.gemm_stress("bf16", 4096, 4096, 4096, seconds=0.5)
     assert g["verified"] == 1 and g["sdc_mismatches"] == 0 and g["launches"] >= 2 and g["tflops"] > 1150, g
     g8 = diag.gemm_stress("mxfp8", 4096, 4096, 4096, seconds=0.5)
-    assert g8["verified"] == 1 and g8["sdc_mismatches"] == 0 and g8["tflops"] > 2200, g8
+    assert g8["verified"] == 1 and g8["sdc_mismatches"] == 0 and g8["tflops"] > 1900, g8
     # every Nth result checked instead of every one: same verdicts
     g = diag.gemm_stress("bf16", 4096, 4096, 4096, seconds=0.3, check_every=8)
     assert g["verified"] == 1 and g["sdc_mismatches"] == 0
