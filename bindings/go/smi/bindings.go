@@ -168,6 +168,9 @@ func deviceStatus(idx uint) (*rawStatus, error) {
 	}, nil
 }
 
+// GM_PROC_MEM_UNKNOWN of gpumon.h.
+const procMemUnknown = ^uint64(0)
+
 type rawProcess struct {
 	pid         uint
 	name        string

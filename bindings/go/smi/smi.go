@@ -166,7 +166,8 @@ func (t ProcessType) String() string {
 type ProcessInfo struct {
 	PID         uint
 	Name        string
-	MemoryUsed  uint64 // MiB
+	MemoryUsed  uint64 // MiB; 0 when MemoryKnown is false
+	MemoryKnown bool   // false: the process holds the device open, the kernel does not report its memory
 	Type        ProcessType
 	CUOccupancy *uint
 }
@@ -403,7 +404,10 @@ func (d *Device) GetAllRunningProcesses() ([]ProcessInfo, error) {
 	}
 	out := make([]ProcessInfo, 0, len(raw))
 	for _, p := range raw {
-		pi := ProcessInfo{PID: p.pid, Name: p.name, MemoryUsed: p.vramBytes >> 20}
+		pi := ProcessInfo{PID: p.pid, Name: p.name, MemoryUsed: p.vramBytes >> 20, MemoryKnown: true}
+		if p.vramBytes == procMemUnknown {
+			pi.MemoryUsed, pi.MemoryKnown = 0, false
+		}
 		if p.cuOccupancy != 0xffffffff {
 			cu := p.cuOccupancy
 			pi.CUOccupancy = &cu

@@ -13,6 +13,8 @@
 //   --prof-period S  seconds between probe runs with --prof-counters=child (default 30: one probe run costs about 0.3 s of CPU; = GPUMON_PROF_PERIOD_S)
 //   -o FILE          publish atomically to FILE (default /run/prometheus/dcgm.prom; "" disables)
 //   -d MS            collection interval, >= 100 (default 1000)
+//   --slow-interval MS   period of the sources that cost a device-library call each and change slowly (error
+//                    counters, bad pages, performance level / power cap, memory usage) when -d is shorter (default 1000)
 //   --listen ADDR    serve /metrics, /gpu/metrics, /healthz (e.g. :9400)
 //   --rest           also serve the REST routes on the listener
 //   --gpus LIST      GPU indices to export ("-1" = all); NODE_NAME env lookup otherwise
@@ -20,6 +22,7 @@
 //   --self-metrics   exporter / engine self metrics
 //   --kubelet-socket PATH   enable pod attribution through the PodResources API
 //   --pod-map FILE   pod map fallback (TSV or kubelet device-plugin checkpoint)
+//   --pod-refresh MS period of the pod-map query, on its own thread and one kept kubelet connection (default 10000)
 //   --resource NAMES device-plugin resource names (default amd.com/gpu)
 //   --diag-results PATH   export the report(s) left by `gpumon-diag --publish` as gpumon_diag_* metrics
 //   --state-file PATH     keep the gpu_last_not_idle_time latch across restarts
@@ -59,7 +62,7 @@ int main(int argc, char** argv) {
   }
   bool embedded = false, profiling = false, once = false, extras = false, self = false, rest = false, legacy = false, health = false;
   std::string out = "/run/prometheus/dcgm.prom", listen, gpus, kubelet, podmap, resource, diagres, statefile;
-  long interval = 1000;
+  long interval = 1000, slow_interval = 0, pod_refresh = 0;
   for (size_t i = 0; i < args.size(); i++) {
     const std::string& a = args[i];
     auto val = [&](std::string* dst) {
@@ -78,6 +81,8 @@ int main(int argc, char** argv) {
     else if (a == "--prof-period") { val(&tmp); setenv("GPUMON_PROF_PERIOD_S", tmp.c_str(), 1); }
     else if (a == "-o") val(&out);
     else if (a == "-d") { val(&tmp); interval = atol(tmp.c_str()); }
+    else if (a == "--slow-interval") { val(&tmp); slow_interval = atol(tmp.c_str()); }
+    else if (a == "--pod-refresh") { val(&tmp); pod_refresh = atol(tmp.c_str()); }
     else if (a == "--listen") val(&listen);
     else if (a == "--rest") rest = true;
     else if (a == "--gpus") val(&gpus);
@@ -138,6 +143,8 @@ int main(int argc, char** argv) {
   cfg.legacy_layout = legacy;
   cfg.health = health;
   cfg.interval_ms = interval;
+  cfg.slow_interval_ms = (int32_t)slow_interval;
+  cfg.pod_refresh_ms = (int32_t)pod_refresh;
   cfg.gpus = gpus.c_str();
   cfg.output_path = out.empty() ? nullptr : out.c_str();
   cfg.listen = listen.empty() ? nullptr : listen.c_str();

@@ -188,6 +188,10 @@ static int cmd_ps(const std::vector<std::string>& a) {
   uint32_t n = 0;
   CLI_CHECK(gm_device_count(&n));
   printf("# gpu   pid   type  mem  Command\n# Idx     #   C/G   MiB  name\n");
+  for (uint32_t g = 0; g < n; g++) {  // where the list comes from on this host (device library table, /proc statistics, open files)
+    char src[32] = "";
+    if (gm_process_source(g, src, sizeof src) == GM_ST_OK) printf("# gpu %u: process list from %s\n", g, src);
+  }
   for (int it = 0; !g_stop && (count == 0 || it < count); it++) {
     if (it) sleep_ms(1000);
     for (uint32_t g = 0; g < n; g++) {
@@ -197,9 +201,11 @@ static int cmd_ps(const std::vector<std::string>& a) {
       if (st != GM_ST_OK && st != GM_ST_INSUFFICIENT_SIZE) np = 0;
       if (np > (int)ps.size()) np = (int)ps.size();
       if (np == 0) printf("%5u %5s %5s %5s %-5s\n", g, "-", "-", "-", "-");
-      for (int i = 0; i < np; i++)
-        printf("%5u %5u %5s %5llu %-5s\n", g, ps[i].pid, ps[i].type == 0 ? "C" : (ps[i].type == 1 ? "G" : "C+G"),
-               (unsigned long long)(ps[i].vram_bytes >> 20), ps[i].name);
+      for (int i = 0; i < np; i++) {
+        char mem[24] = "N/A";  // a holder of the device whose memory the kernel does not report
+        if (ps[i].vram_bytes != GM_PROC_MEM_UNKNOWN) snprintf(mem, sizeof mem, "%llu", (unsigned long long)(ps[i].vram_bytes >> 20));
+        printf("%5u %5u %5s %5s %-5s\n", g, ps[i].pid, ps[i].type == 0 ? "C" : (ps[i].type == 1 ? "G" : "C+G"), mem, ps[i].name);
+      }
     }
     fflush(stdout);
   }

@@ -28,6 +28,7 @@
 #include "../prof/prof_child.h"
 #include "../prof/prof_counters.h"
 #include "backend.h"
+#include "procscan.h"
 
 namespace gpumon {
 namespace {
@@ -139,6 +140,7 @@ struct Dev {
   GpuStatic st;
   uint64_t bdf_key = 0;
   uint32_t partition_id = 0;
+  ProcSource proc_source = ProcSource::NONE;  // where the last process list came from
   double energy_resolution_uj = 15.259;  // µJ per accumulator tick, refined at init
   // throttle-residency calibration and edge detection
   uint64_t prev_acc_counter = 0, prev_fw_ts = 0;
@@ -320,15 +322,29 @@ class AmdSmiBackend : public Backend {
     return any_ok ? GM_ST_OK : GM_ST_GENERIC_ERROR;
   }
 
+  const char* process_source(uint32_t gpu) override {
+    return gpu < devs_.size() ? proc_source_name(devs_[gpu].proc_source) : "none";
+  }
+
   gm_status_t processes(uint32_t gpu, std::vector<ProcSample>* out) override {
     out->clear();
     if (gpu >= devs_.size()) return GM_ST_BADPARAM;
-    if (!api_.amdsmi_get_gpu_process_list) return GM_ST_NOT_SUPPORTED;
     // The library builds its list from the KFD process table.  Where that directory is missing or closed
-    // (containers with a partial sysfs, non-root users on some hosts) it reports an EMPTY list as success
-    // and complains on stderr at every call: say what is true instead, and stay quiet.
+    // (containers with a partial sysfs, guests, non-root users on some hosts) it reports an EMPTY list as success
+    // and complains on stderr at every call.  There the kernel's per-file DRM statistics under /proc answer
+    // instead (core/backend/procscan.h): every process this one may look into, with memory and engine time where
+    // the kernel writes them and as a bare holder of the render node where it does not.
     static const int kfd_errno = access("/sys/class/kfd/kfd/proc", R_OK | X_OK) == 0 ? 0 : errno;
-    if (kfd_errno) return kfd_errno == EACCES ? GM_ST_NO_PERMISSION : GM_ST_NOT_SUPPORTED;
+    if (kfd_errno || !api_.amdsmi_get_gpu_process_list) {
+      static const std::string proc_root = getenv("GPUMON_PROC_ROOT") ? getenv("GPUMON_PROC_ROOT") : "/proc";
+      ProcScan scan;
+      scan_gpu_processes(proc_root, devs_[gpu].st.pci_bdf, devs_[gpu].st.drm_render_minor, &scan);
+      devs_[gpu].proc_source = scan.source;
+      if (scan.source == ProcSource::NONE) return kfd_errno == EACCES ? GM_ST_NO_PERMISSION : GM_ST_NOT_SUPPORTED;
+      *out = std::move(scan.procs);
+      return GM_ST_OK;
+    }
+    devs_[gpu].proc_source = ProcSource::KFD;
     uint32_t n = 64;
     std::vector<amdsmi_proc_info_t> list;
     amdsmi_status_t rc = AMDSMI_STATUS_SUCCESS;
@@ -1008,7 +1024,11 @@ class AmdSmiBackend : public Backend {
       const bool any_low = device_residency(low_xcc, AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC, &low);
       const bool any_host = device_residency(host_xcc, AMDSMI_MAX_NUM_XCP * AMDSMI_MAX_NUM_XCC, &host);
       if (any_low) out->set_i(GM_FI_LOW_UTIL_VIOLATION, us(3, low)); else out->set_blank(GM_FI_LOW_UTIL_VIOLATION, GM_VS_NOT_SUPPORTED);
-      if (any_host) out->set_i(GM_FI_RELIABILITY_VIOLATION, us(4, host)); else out->set_blank(GM_FI_RELIABILITY_VIOLATION, GM_VS_NOT_SUPPORTED);
+      // "Below the host limit" is true of every idle GPU and of every power-limited one: it is exported under its
+      // own name.  The contract's "throttling due to reliability constraints" has no counterpart in this firmware
+      // and stays blank, so that a dashboard that alerts on it does not fire on every idle MI355X.
+      if (any_host) out->set_i(GM_FI_GFX_BELOW_HOST_LIMIT, us(4, host)); else out->set_blank(GM_FI_GFX_BELOW_HOST_LIMIT, GM_VS_NOT_SUPPORTED);
+      out->set_blank(GM_FI_RELIABILITY_VIOLATION, GM_VS_NOT_SUPPORTED);
       // Active reasons = accumulators that moved between two DISTINCT firmware tables.  The firmware refreshes the
       // table on its own cadence (about once a second); a watch faster than that reads the same table several
       // times, and comparing equal tables would clear every reason between refreshes.

@@ -91,7 +91,7 @@ struct Sample {
 struct ProcSample {
   uint32_t pid = 0;
   std::string name;
-  uint64_t vram_bytes = 0, gtt_bytes = 0, cpu_mem_bytes = 0;
+  uint64_t vram_bytes = 0, gtt_bytes = 0, cpu_mem_bytes = 0;  // ~0 = not known (GM_PROC_MEM_UNKNOWN)
   uint64_t gfx_engine_ns = 0, enc_engine_ns = 0;
   uint32_t cu_occupancy = 0xffffffffu;
 };
@@ -145,6 +145,9 @@ class Backend {
   // Fills `out` for the requested Source bits; never throws, never blocks long.
   virtual gm_status_t sample(uint32_t gpu, uint32_t sources, Sample* out) = 0;
   virtual gm_status_t processes(uint32_t gpu, std::vector<ProcSample>* out) = 0;
+  // Where the last processes() answer for this GPU came from: "kfd" (the device library's table), "fdinfo"
+  // (the kernel's per-file DRM statistics), "open-files" (holders of the render node, no figures), "fake", "none".
+  virtual const char* process_source(uint32_t gpu) { (void)gpu; return "none"; }
   virtual gm_status_t peer_link(uint32_t gpu, uint32_t peer, PeerLink* out) = 0;
   // Every physical xGMI link of the GPU, in the index order of the per-link telemetry fields.
   virtual gm_status_t xgmi_links(uint32_t gpu, std::vector<XgmiLink>* out) {

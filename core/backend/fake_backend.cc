@@ -328,6 +328,7 @@ class FakeBackend : public Backend {
     return failing && !ok ? GM_ST_GENERIC_ERROR : GM_ST_OK;
   }
 
+  const char* process_source(uint32_t) override { return "fake"; }
   gm_status_t processes(uint32_t gpu, std::vector<ProcSample>* out) override {
     std::lock_guard<std::mutex> l(mu_);
     if (gpu >= gpus_.size()) return GM_ST_BADPARAM;

@@ -11,6 +11,7 @@
 
 extern char** environ;
 
+#include "backend/procscan.h"
 #include "common/util.h"
 #include "engine/engine.h"
 #include "exporter/exporter.h"
@@ -482,6 +483,33 @@ gm_status_t gm_device_processes(uint32_t gpu, gm_process_t* out, int* n) {
   for (size_t i = 0; i < v.size(); i++) out[i] = v[i];
   return GM_ST_OK;
 }
+gm_status_t gm_process_source(uint32_t gpu, char* buf, size_t cap) {
+  REQUIRE_ENGINE();
+  if (!buf || !cap) return GM_ST_BADPARAM;
+  std::string s;
+  gm_status_t st = e->process_source(gpu, &s);
+  snprintf(buf, cap, "%s", s.c_str());
+  return st;
+}
+gm_status_t gm_proc_scan(const char* proc_root, const char* pci_bdf, int render_minor, gm_process_t* out, int* n, char* source, size_t cap) {
+  if (!proc_root || !n || *n < 0 || (!out && *n > 0)) return GM_ST_BADPARAM;
+  gpumon::ProcScan scan;
+  gpumon::scan_gpu_processes(proc_root, pci_bdf ? pci_bdf : "", render_minor, &scan);
+  if (source && cap) snprintf(source, cap, "%s", gpumon::proc_source_name(scan.source));
+  const int capn = *n;
+  *n = (int)scan.procs.size();
+  for (int i = 0; i < *n && i < capn; i++) {
+    gm_process_t& o = out[i];
+    memset(&o, 0, sizeof o);
+    o.pid = scan.procs[i].pid;
+    o.vram_bytes = scan.procs[i].vram_bytes;
+    o.gtt_bytes = scan.procs[i].gtt_bytes;
+    o.gfx_engine_ns = scan.procs[i].gfx_engine_ns;
+    o.cu_occupancy = scan.procs[i].cu_occupancy;
+    gpumon::copy_str(o.name, scan.procs[i].name);
+  }
+  return *n > capn ? GM_ST_INSUFFICIENT_SIZE : GM_ST_OK;
+}
 gm_status_t gm_device_mode(uint32_t gpu, gm_device_mode_t* out) {
   REQUIRE_ENGINE();
   if (!out) return GM_ST_BADPARAM;
@@ -731,6 +759,8 @@ gm_status_t gm_exporter_create(const gm_exporter_config_t* c, gm_exporter_t* out
   if (c->diag_results_path) cfg.diag_results_path = c->diag_results_path;
   if (c->state_path) cfg.state_path = c->state_path;
   cfg.health = c->health != 0;
+  if (c->slow_interval_ms > 0) cfg.slow_interval_ms = c->slow_interval_ms;
+  if (c->pod_refresh_ms > 0) cfg.pod_refresh_ms = c->pod_refresh_ms;
   auto ex = std::make_shared<Exporter>(e, cfg);
   gm_status_t st = ex->init();
   if (st != GM_ST_OK) return st;

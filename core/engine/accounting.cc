@@ -110,7 +110,7 @@ void LocalEngine::accounting_tick(int64_t now_mono, int64_t now_wall) {
         for (int i = 0; i < 5; i++) a.viol0[i] = viol[i];
       }
       a.last_seen_mono = now_mono;
-      a.max_vram = std::max(a.max_vram, p.vram_bytes);
+      if (p.vram_bytes != GM_PROC_MEM_UNKNOWN) a.max_vram = std::max(a.max_vram, p.vram_bytes), a.have_vram = true;
       a.last_engine_ns = p.gfx_engine_ns;
       a.have_engine = p.gfx_engine_ns != 0;
       double sh = share[p.pid];
@@ -185,7 +185,7 @@ gm_status_t LocalEngine::pid_info(gm_group_t g, uint32_t pid, gm_pid_info_t* out
     if (a.pcie_rx0 >= 0 && a.pcie_rx1 >= 0 && life_s > 0) { s.pcie_rx_avg_kbs = (int64_t)((double)(a.pcie_rx1 - a.pcie_rx0) / life_s); set(5); }
     if (a.pcie_tx0 >= 0 && a.pcie_tx1 >= 0 && life_s > 0) { s.pcie_tx_avg_kbs = (int64_t)((double)(a.pcie_tx1 - a.pcie_tx0) / life_s); set(6); }
     if (a.replay0 >= 0 && a.replay1 >= 0) { s.pcie_replays = a.replay1 - a.replay0; set(7); }
-    s.max_vram_bytes = (int64_t)a.max_vram; set(8);
+    if (a.have_vram) { s.max_vram_bytes = (int64_t)a.max_vram; set(8); }
     if (a.ce0 >= 0 && a.ce1 >= 0) { s.ecc_ce = a.ce1 - a.ce0; set(9); }
     if (a.ue0 >= 0 && a.ue1 >= 0) { s.ecc_ue = a.ue1 - a.ue0; set(10); }
     int64_t* vout[5] = {&s.power_violation_us, &s.thermal_violation_us, &s.reliability_violation_us,

@@ -1130,6 +1130,14 @@ gm_status_t LocalEngine::device_processes(uint32_t gpu, std::vector<gm_process_t
   return GM_ST_OK;
 }
 
+gm_status_t LocalEngine::process_source(uint32_t gpu, std::string* out) {
+  if (gpu >= gpus_.size()) return GM_ST_BADPARAM;
+  std::vector<ProcSample> ps;
+  gm_status_t st = backend_->processes(gpu, &ps);  // the source is known once the list was asked for
+  *out = backend_->process_source(gpu);
+  return st == GM_ST_OK || st == GM_ST_NOT_SUPPORTED || st == GM_ST_NO_PERMISSION ? GM_ST_OK : st;
+}
+
 gm_status_t LocalEngine::device_mode(uint32_t gpu, gm_device_mode_t* out) {
   if (gpu >= gpus_.size()) return GM_ST_BADPARAM;
   uint32_t ver = out->version;

@@ -56,6 +56,8 @@ class Engine {
 
   virtual gm_status_t device_status(uint32_t gpu, gm_device_status_t* out) = 0;
   virtual gm_status_t device_processes(uint32_t gpu, std::vector<gm_process_t>* out) = 0;
+  // Where the process list of this GPU comes from on this host ("kfd", "fdinfo", "open-files", "fake", "none").
+  virtual gm_status_t process_source(uint32_t gpu, std::string* out) = 0;
   virtual gm_status_t device_mode(uint32_t gpu, gm_device_mode_t* out) = 0;
 
   virtual gm_status_t health_set(gm_group_t g, uint32_t systems) = 0;
@@ -141,6 +143,7 @@ class LocalEngine : public Engine {
   gm_status_t fake_ctl(const std::string& cmd) override;
   gm_status_t device_status(uint32_t gpu, gm_device_status_t* out) override;
   gm_status_t device_processes(uint32_t gpu, std::vector<gm_process_t>* out) override;
+  gm_status_t process_source(uint32_t gpu, std::string* out) override;
   gm_status_t device_mode(uint32_t gpu, gm_device_mode_t* out) override;
   gm_status_t health_set(gm_group_t g, uint32_t systems) override;
   gm_status_t health_get(gm_group_t g, uint32_t* systems) override;
@@ -237,6 +240,7 @@ class LocalEngine : public Engine {
     double sum_gfx = 0, sum_mem = 0, sum_gfxclk = 0, sum_memclk = 0, sum_share = 0;
     uint64_t nsamples = 0;
     uint64_t max_vram = 0;
+    bool have_vram = false;  // false while the process list carries no memory figures
     uint64_t last_engine_ns = 0;
     bool have_engine = false;
     int64_t pcie_rx0 = -1, pcie_tx0 = -1, pcie_rx1 = -1, pcie_tx1 = -1, replay0 = -1, replay1 = -1;

@@ -23,6 +23,7 @@ struct Family {
   const char* type;
   std::vector<Member> members;
   bool last_not_idle = false;  // the synthesised gpu_last_not_idle_time family
+  bool from_counters = false;  // fed by the hardware-counter plugin: sampled values in its child mode
 };
 
 const char* kBlockNames[] = {"umc", "gfx", "sdma", "mmhub", "xgmi"};
@@ -42,6 +43,7 @@ std::vector<Family> build_families(bool profiling, bool extras) {
       fam->help = f->prom_help;
       fam->type = f->prom_type == 2 ? "counter" : "gauge";
     }
+    if (id == GM_FI_PROF_MFMA_ACTIVE || id == GM_FI_PROF_CU_ACTIVE || id == GM_FI_PROF_MEM_PIPE_ACTIVE) fam->from_counters = true;
     Member m;
     m.field = id;
     m.label = f->extra_label;
@@ -96,6 +98,16 @@ void append_value(std::string* out, const gm_value_t& v) {
 
 Exporter::Exporter(Engine* engine, const ExporterConfig& cfg) : engine_(engine), cfg_(cfg) {
   if (cfg_.interval_ms < 100) cfg_.interval_ms = 100;  // same floor as the reference's -d
+  // The counter plugin's child mode delivers duty-cycle samples, not integrals: the HELP text says so, with the
+  // numbers (three counter windows per probe run, one run per period).
+  const char* mode = getenv("GPUMON_PROF_COUNTERS");
+  if (mode && !strcmp(mode, "child")) {
+    const char* pe = getenv("GPUMON_PROF_PERIOD_S");
+    const char* we = getenv("GPUMON_PROF_WINDOW_MS");
+    const double period = pe && atof(pe) > 0 ? atof(pe) : 30.0;
+    const int window_ms = we && atoi(we) > 0 ? atoi(we) : 250;
+    counter_note_ = strprintf(" Sampled: about %.2f s of counting every %.0f s.", 3 * window_ms / 1000.0, period);
+  }
 }
 
 Exporter::~Exporter() {
@@ -105,6 +117,10 @@ Exporter::~Exporter() {
   if (watching_) {
     engine_->unwatch_fields(group_, fg_);
     engine_->field_group_destroy(fg_);
+    if (fg_slow_) {
+      engine_->unwatch_fields(group_, fg_slow_);
+      engine_->field_group_destroy(fg_slow_);
+    }
     engine_->group_destroy(group_);
   }
 }
@@ -170,10 +186,25 @@ gm_status_t Exporter::init() {
   if (st != GM_ST_OK) return st;
   for (uint32_t g : gpus_)
     if ((st = engine_->group_add(group_, g)) != GM_ST_OK) return st;
-  st = engine_->field_group_create(fields_, tag, &fg_);
+  // Two schedules.  Almost every exported value comes out of the one bulk metrics table a GPU hands over per
+  // tick; error counters, the bad-page table, performance level / power cap and memory usage are a device-library
+  // call each and do not change at 10 Hz.  With a collection interval under slow_interval_ms those sources keep
+  // the slower period, so a 100 ms exporter costs little more than the bulk read.
+  std::vector<uint16_t> fast, slow;
+  const uint32_t kSlowSources = SRC_ECC | SRC_BAD_PAGES | SRC_PERF | SRC_VRAM;
+  const bool split = cfg_.slow_interval_ms > cfg_.interval_ms;
+  for (uint16_t id : fields_) {
+    const FieldDef* f = field_def(id);
+    (split && f && (f->source & kSlowSources) ? slow : fast).push_back(id);
+  }
+  st = engine_->field_group_create(fast, tag, &fg_);
   if (st != GM_ST_OK) return st;
   st = engine_->watch_fields(group_, fg_, cfg_.interval_ms * 1000, GM_DEFAULT_MAX_KEEP_AGE_S, 2);
   if (st != GM_ST_OK) return st;
+  if (!slow.empty()) {
+    if ((st = engine_->field_group_create(slow, tag + "-slow", &fg_slow_)) != GM_ST_OK) return st;
+    if ((st = engine_->watch_fields(group_, fg_slow_, cfg_.slow_interval_ms * 1000, GM_DEFAULT_MAX_KEEP_AGE_S, 2)) != GM_ST_OK) return st;
+  }
   watching_ = true;
   if (cfg_.self_metrics) engine_->introspect_toggle(true);
   if (cfg_.health) {
@@ -252,12 +283,16 @@ void Exporter::set_pod_map(const PodMap& m) {
   pod_map_ = m;
 }
 
+// Runs on the caller's thread at start-up and on the pod thread afterwards, never on the publish thread: a kubelet
+// that does not answer holds up nothing but the next pod map.
 void Exporter::refresh_pod_map() {
   PodMap m;
   bool ok = false;
   if (!cfg_.kubelet_socket.empty()) {
     std::string err;
-    gm_status_t st = kubelet_list_pod_resources(cfg_.kubelet_socket, cfg_.resource_names, 10000, &m, &err);
+    if (!kubelet_) kubelet_.reset(new KubeletClient(cfg_.kubelet_socket, cfg_.resource_names));
+    gm_status_t st = kubelet_->list(10000, &m, &err);
+    kubelet_connects_ = kubelet_->connects();
     ok = st == GM_ST_OK;
     if (!ok) GM_LOGW("pod attribution: kubelet query failed: %s", err.c_str());
   }
@@ -269,6 +304,7 @@ void Exporter::refresh_pod_map() {
     }
   }
   pod_map_ok_ = ok ? 1 : 0;
+  pod_refreshes_++;
   last_pod_refresh_mono_ = monotonic_us();
   if (ok) set_pod_map(m);  // on failure keep the last good map
 }
@@ -353,6 +389,7 @@ void Exporter::render(std::string* out) {
     *out += fam.name;
     *out += " ";
     *out += fam.help;
+    if (fam.from_counters) *out += counter_note_;
     *out += "\n# TYPE ";
     *out += fam.name;
     *out += " ";
@@ -472,7 +509,12 @@ void Exporter::render_self(std::string* out) {
   gauge("gpumon_exporter_sweeps_total", "File sweeps published.", (double)sweeps_, "counter");
   gauge("gpumon_exporter_scrapes_total", "HTTP scrapes served.", (double)scrapes_, "counter");
   gauge("gpumon_exporter_publish_errors_total", "File publishes that failed.", (double)publish_errors_, "counter");
-  if (pod_map_ok_ >= 0) gauge("gpumon_exporter_pod_map_up", "1 if the last pod-resources query succeeded.", (double)pod_map_ok_);
+  if (pod_map_ok_ >= 0) {
+    gauge("gpumon_exporter_pod_map_up", "1 if the last pod-resources query succeeded.", (double)pod_map_ok_);
+    gauge("gpumon_exporter_pod_map_refreshes_total", "Pod-map queries made (kubelet or file).", (double)pod_refreshes_, "counter");
+    if (!cfg_.kubelet_socket.empty())
+      gauge("gpumon_exporter_kubelet_connects_total", "Connections opened to the kubelet (one is kept between queries).", (double)kubelet_connects_, "counter");
+  }
 }
 
 gm_status_t Exporter::publish() {
@@ -539,14 +581,24 @@ void Exporter::loop() {
     }
     if (!running_) break;
     if ((st = publish()) != GM_ST_OK) GM_LOGW("exporter publish failed: %s", status_string(st));
-    // Pod map on its own slower schedule instead of one kubelet dial per sweep
-    // (the reference dials once a second: src/watchers.go:41).
-    if ((!cfg_.kubelet_socket.empty() || !cfg_.pod_map_path.empty()) &&
-        monotonic_us() - last_pod_refresh_mono_ >= std::min<int64_t>(10000000, std::max<int64_t>(interval, 1000000)))
-      refresh_pod_map();
     next += interval;
     int64_t now = monotonic_us();
     if (next <= now) next = now + interval;
+  }
+}
+
+// The pod map on a schedule and a thread of its own: one kept connection to the kubelet, asked every
+// pod_refresh_ms (the reference dials anew once a second, on the path that publishes: src/watchers.go:41).
+void Exporter::pod_loop() {
+  const int64_t period = std::max<int64_t>(cfg_.pod_refresh_ms, 100) * 1000;
+  while (running_) {
+    {
+      std::unique_lock<std::mutex> l(wake_mu_);
+      const int64_t due = last_pod_refresh_mono_ + period, now = monotonic_us();
+      if (due > now) cv_wait_for(wake_cv_, l, std::chrono::microseconds(due - now), [&] { return !running_.load(); });
+    }
+    if (!running_) break;
+    refresh_pod_map();
   }
 }
 
@@ -559,6 +611,7 @@ gm_status_t Exporter::start() {
     }
   }
   th_ = std::thread([this] { loop(); });
+  if (!cfg_.kubelet_socket.empty() || !cfg_.pod_map_path.empty()) pod_th_ = std::thread([this] { pod_loop(); });
   return GM_ST_OK;
 }
 
@@ -566,6 +619,7 @@ void Exporter::stop() {
   if (!running_.exchange(false)) return;
   wake_cv_.notify_all();
   if (th_.joinable()) th_.join();
+  if (pod_th_.joinable()) pod_th_.join();
   http_.stop();
 }
 

@@ -37,6 +37,28 @@ std::string relabel_text(const std::string& text, const PodMap& m, const std::st
 gm_status_t kubelet_list_pod_resources(const std::string& socket_path, const std::string& resource_names,
                                        int timeout_ms, PodMap* out, std::string* error);
 
+// The same call on a connection that is kept between calls (the reference dials the kubelet anew once a second:
+// src/watchers.go:41 -> kubelet_server.go:36-41).  A connection that went away (kubelet restart, GOAWAY) is replaced
+// once per call.  Not thread safe: one owner.
+class KubeletClient {
+ public:
+  KubeletClient(const std::string& socket_path, const std::string& resource_names);
+  ~KubeletClient();
+  KubeletClient(const KubeletClient&) = delete;
+  KubeletClient& operator=(const KubeletClient&) = delete;
+  gm_status_t list(int timeout_ms, PodMap* out, std::string* error);
+  uint64_t connects() const { return connects_; }  // connections opened so far
+
+ private:
+  struct Impl;
+  void disconnect();
+  gm_status_t connect_now(std::string* error);
+  gm_status_t list_once(PodMap* out, std::string* error, bool* transport);
+  std::string socket_path_, resource_names_;
+  Impl* impl_;
+  uint64_t connects_ = 0;
+};
+
 struct ExporterConfig {
   bool profiling = false;
   bool amd_extras = false;
@@ -45,6 +67,10 @@ struct ExporterConfig {
   bool legacy_layout = false;
   bool health = false;  // health check of every exported GPU once per sweep, exported as gpumon_health_*
   int64_t interval_ms = 1000;
+  // Sources that cost a device-library call of their own and change slowly (error counters, bad pages, performance
+  // level and power cap, memory usage) are sampled at this period when the collection interval is shorter.
+  int64_t slow_interval_ms = 1000;
+  int64_t pod_refresh_ms = 10000;  // how often the pod map is asked for (kubelet or file), on a thread of its own
   std::string gpus;  // "" / "-1" = all
   std::string output_path;
   std::string listen;
@@ -71,6 +97,7 @@ class Exporter {
 
  private:
   void loop();
+  void pod_loop();
   void refresh_pod_map();
   void handle_http(const HttpRequest& req, HttpResponse* resp);
   void render_self(std::string* out);
@@ -87,8 +114,10 @@ class Exporter {
   std::vector<std::vector<int>> link_peer_;  // per exported entry: GPU index at the far end of xGMI link l, -1 = unknown
   std::vector<uint16_t> fields_;  // every field id fetched per GPU
   gm_group_t group_ = 0;
-  gm_field_group_t fg_ = 0;
+  gm_field_group_t fg_ = 0, fg_slow_ = 0;  // per-tick fields; fields of the slow sources (0 = none split off)
   bool watching_ = false;
+  std::unique_ptr<KubeletClient> kubelet_;  // owned by whoever refreshes the pod map: init(), then the pod thread
+  std::thread pod_th_;
 
   std::mutex mu_;  // last_not_idle_, pod_map_, cached text
   std::map<uint32_t, int64_t> last_not_idle_;
@@ -113,6 +142,7 @@ class Exporter {
   std::vector<std::array<uint64_t, kPolicyConditions>> violations_;
   gm_policy_reg_t policy_reg_ = 0;
   bool policy_registered_ = false;
+  std::string counter_note_;  // appended to the HELP of the counter-fed families when their values are samples
   std::string cached_;  // last published text (served over HTTP between sweeps)
   std::vector<gm_value_t> scratch_;
 
@@ -125,6 +155,7 @@ class Exporter {
   std::atomic<uint64_t> sweeps_{0}, scrapes_{0}, publish_errors_{0};
   std::atomic<int64_t> last_render_us_{0}, last_sweep_us_{0}, last_pod_refresh_mono_{0};
   std::atomic<int> pod_map_ok_{-1};
+  std::atomic<uint64_t> pod_refreshes_{0}, kubelet_connects_{0};
 };
 
 // REST routes of the reference's sample server (bindings/go/samples/dcgm/restApi/

@@ -25,8 +25,9 @@ const uint32_t kWindow = 16u * 1024 * 1024;  // the reference's 16 MiB receive c
 
 struct Conn {
   int fd = -1;
-  int64_t deadline_us;
+  int64_t deadline_us = 0;
   std::string err;
+  uint64_t consumed = 0;  // DATA bytes received since the connection window was last topped up
 
   bool wait(short ev) {
     while (true) {
@@ -212,7 +213,7 @@ int unary_call(Conn& c, uint32_t stream, const std::string& path, std::string* m
   out += frame(F_DATA, 0x1 /*END_STREAM*/, stream, std::string("\0\0\0\0\0", 5));  // empty ListPodResourcesRequest
   if (!c.send_all(out)) return -1;
   std::string body, trailer_block;
-  uint64_t consumed = 0;
+  uint64_t consumed = 0;  // of this stream's window
   while (true) {
     char hdr[9];
     if (!c.recv_n(hdr, 9)) return -1;
@@ -256,12 +257,18 @@ int unary_call(Conn& c, uint32_t stream, const std::string& path, std::string* m
           body.append(payload, off, n - off);
           if (body.size() > kWindow) { c.err = "response larger than 16 MiB"; return -1; }
           consumed += len;
-          if (consumed > kWindow / 2) {  // top the flow-control windows back up
-            std::string wu = u32be((uint32_t)consumed);
-            if (!c.send_all(frame(F_WINDOW, 0, 0, wu) + frame(F_WINDOW, 0, stream, wu))) return -1;
+          if (consumed > kWindow / 2) {  // top the stream's flow-control window back up
+            if (!c.send_all(frame(F_WINDOW, 0, stream, u32be((uint32_t)consumed)))) return -1;
             consumed = 0;
           }
           end_stream = flags & 0x1;
+        }
+        // the connection's window is charged for every DATA frame, whichever stream it belongs to, and lives as
+        // long as the connection does
+        c.consumed += len;
+        if (c.consumed > kWindow / 2) {
+          if (!c.send_all(frame(F_WINDOW, 0, 0, u32be((uint32_t)c.consumed)))) return -1;
+          c.consumed = 0;
         }
         break;
       default: break;
@@ -284,36 +291,56 @@ int unary_call(Conn& c, uint32_t stream, const std::string& path, std::string* m
 
 }  // namespace
 
-gm_status_t kubelet_list_pod_resources(const std::string& socket_path, const std::string& resource_names,
-                                       int timeout_ms, PodMap* out, std::string* error) {
+// ---- persistent client ---------------------------------------------------------
+struct KubeletClient::Impl {
   Conn c;
-  c.deadline_us = monotonic_us() + (int64_t)timeout_ms * 1000;
+  uint32_t next_stream = 1;
+  int service = 0;  // index into kPaths of the service that answered last
+};
+
+static const char* kPaths[] = {"/v1.PodResourcesLister/List", "/v1alpha1.PodResourcesLister/List"};
+
+KubeletClient::KubeletClient(const std::string& socket_path, const std::string& resource_names)
+    : socket_path_(socket_path), resource_names_(resource_names), impl_(new Impl) {}
+
+KubeletClient::~KubeletClient() {
+  disconnect();
+  delete impl_;
+}
+
+void KubeletClient::disconnect() {
+  if (impl_->c.fd >= 0) close(impl_->c.fd);
+  impl_->c.fd = -1;
+}
+
+gm_status_t KubeletClient::connect_now(std::string* error) {
+  Conn& c = impl_->c;
   sockaddr_un sa;
   memset(&sa, 0, sizeof sa);
   sa.sun_family = AF_UNIX;
-  if (socket_path.size() >= sizeof sa.sun_path) {
-    if (error) *error = "socket path too long";
+  if (socket_path_.size() >= sizeof sa.sun_path) {
+    *error = "socket path too long";
     return GM_ST_BADPARAM;
   }
-  strcpy(sa.sun_path, socket_path.c_str());
+  strcpy(sa.sun_path, socket_path_.c_str());
   c.fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC | SOCK_NONBLOCK, 0);
   if (c.fd < 0) {
-    if (error) *error = strerror(errno);
+    *error = strerror(errno);
     return GM_ST_CONNECTION_NOT_VALID;
   }
   auto fail = [&](gm_status_t st, const std::string& msg) {
-    if (error) *error = msg;
-    close(c.fd);
+    *error = msg;
+    disconnect();
     return st;
   };
   if (connect(c.fd, (sockaddr*)&sa, sizeof sa) != 0) {
     if (errno != EINPROGRESS && errno != EAGAIN)
-      return fail(GM_ST_CONNECTION_NOT_VALID, strprintf("failure connecting to %s: %s", socket_path.c_str(), strerror(errno)));
+      return fail(GM_ST_CONNECTION_NOT_VALID, strprintf("failure connecting to %s: %s", socket_path_.c_str(), strerror(errno)));
     if (!c.wait(POLLOUT)) return fail(GM_ST_TIMEOUT, "connect: " + c.err);
     int soerr = 0;
     socklen_t sl = sizeof soerr;
     getsockopt(c.fd, SOL_SOCKET, SO_ERROR, &soerr, &sl);
-    if (soerr) return fail(GM_ST_CONNECTION_NOT_VALID, strprintf("failure connecting to %s: %s", socket_path.c_str(), strerror(soerr)));
+    if (soerr) return fail(GM_ST_CONNECTION_NOT_VALID, strprintf("failure connecting to %s: %s", socket_path_.c_str(), strerror(soerr)));
   }
   std::string hello = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";
   std::string settings;
@@ -322,22 +349,81 @@ gm_status_t kubelet_list_pod_resources(const std::string& socket_path, const std
   hello += frame(F_SETTINGS, 0, 0, settings);
   hello += frame(F_WINDOW, 0, 0, u32be(kWindow - 65535));
   if (!c.send_all(hello)) return fail(GM_ST_CONNECTION_NOT_VALID, c.err);
+  impl_->next_stream = 1;
+  c.consumed = 0;
+  connects_++;
+  return GM_ST_OK;
+}
 
-  static const char* paths[] = {"/v1.PodResourcesLister/List", "/v1alpha1.PodResourcesLister/List"};
-  uint32_t stream = 1;
-  for (const char* path : paths) {
+// One List() on the connection as it is.  *transport = the connection is no longer usable.
+gm_status_t KubeletClient::list_once(PodMap* out, std::string* error, bool* transport) {
+  Conn& c = impl_->c;
+  *transport = false;
+  // the service that answered last time first; the other one if that one is gone (a kubelet upgrade)
+  for (int k = 0; k < 2; k++) {
+    const int svc = (impl_->service + k) % 2;
     std::string msg;
-    int rc = unary_call(c, stream, path, &msg);
-    stream += 2;
-    if (rc < 0) return fail(c.err == "timed out" ? GM_ST_TIMEOUT : GM_ST_CONNECTION_NOT_VALID, "failure getting pod resources: " + c.err);
-    if (rc == 0) continue;  // not served under this name: try the older service
+    const uint32_t stream = impl_->next_stream;
+    impl_->next_stream += 2;
+    int rc = unary_call(c, stream, kPaths[svc], &msg);
+    if (rc < 0) {
+      *transport = true;
+      *error = "failure getting pod resources: " + c.err;
+      return c.err == "timed out" ? GM_ST_TIMEOUT : GM_ST_CONNECTION_NOT_VALID;
+    }
+    if (rc == 0) continue;  // not served under this name: try the other service
+    impl_->service = svc;
     out->clear();
-    if (!decode_list_response((const uint8_t*)msg.data(), msg.size(), resource_names, out))
-      return fail(GM_ST_GENERIC_ERROR, "malformed ListPodResourcesResponse");
-    close(c.fd);
+    if (!decode_list_response((const uint8_t*)msg.data(), msg.size(), resource_names_, out)) {
+      *error = "malformed ListPodResourcesResponse";
+      return GM_ST_GENERIC_ERROR;
+    }
     return GM_ST_OK;
   }
-  return fail(GM_ST_NOT_SUPPORTED, "failure getting pod resources: " + c.err);
+  *error = "failure getting pod resources: " + c.err;
+  return GM_ST_NOT_SUPPORTED;
+}
+
+gm_status_t KubeletClient::list(int timeout_ms, PodMap* out, std::string* error) {
+  std::string err;
+  Conn& c = impl_->c;
+  c.deadline_us = monotonic_us() + (int64_t)timeout_ms * 1000;
+  c.err.clear();
+  // A connection kept from the last call may have been closed under us (kubelet restart, GOAWAY): one fresh
+  // connection is tried before the call counts as failed.  A timeout is not retried: the time is spent.
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const bool reused = c.fd >= 0 && impl_->next_stream < (1u << 30);
+    if (!reused) {
+      disconnect();
+      gm_status_t st = connect_now(&err);
+      if (st != GM_ST_OK) {
+        if (error) *error = err;
+        return st;
+      }
+    }
+    bool transport = false;
+    gm_status_t st = list_once(out, &err, &transport);
+    if (!transport) {
+      if (error && st != GM_ST_OK) *error = err;
+      return st;
+    }
+    disconnect();
+    if (!reused || st == GM_ST_TIMEOUT) {
+      if (error) *error = err;
+      return st;
+    }
+  }
+  if (error) *error = err;
+  return GM_ST_CONNECTION_NOT_VALID;
+}
+
+gm_status_t kubelet_list_pod_resources(const std::string& socket_path, const std::string& resource_names,
+                                       int timeout_ms, PodMap* out, std::string* error) {
+  KubeletClient k(socket_path, resource_names);
+  std::string err;
+  gm_status_t st = k.list(timeout_ms, out, &err);
+  if (error) *error = err;
+  return st;
 }
 
 }  // namespace gpumon

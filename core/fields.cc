@@ -89,6 +89,7 @@ std::vector<FieldDef> build_table() {
     {GM_FI_BOARD_LIMIT_VIOLATION, I64, SRC_VIOLATION, "board_limit_violation", "us", COUNTER, 0, "dcgm_board_limit_violation", "Throttling duration due to board limit constraints (in us).", nullptr, 0},
     {GM_FI_LOW_UTIL_VIOLATION,    I64, SRC_VIOLATION, "low_util_violation", "us", COUNTER, 0, "dcgm_low_util_violation", "Throttling duration due to low utilization (in us).", nullptr, 0},
     {GM_FI_RELIABILITY_VIOLATION, I64, SRC_VIOLATION, "reliability_violation", "us", COUNTER, 0, "dcgm_reliability_violation", "Throttling duration due to reliability constraints (in us).", nullptr, 0},
+    {GM_FI_GFX_BELOW_HOST_LIMIT,  I64, SRC_VIOLATION, "gfx_below_host_limit", "us", COUNTER, 2, "gpumon_gfx_clock_below_host_limit_us", "Time the shader clock has spent below the limit set by the host, for whatever reason, idling included (in us).", nullptr, 0},
     {GM_FI_THROTTLE_STATUS,       I64, SRC_VIOLATION, "throttle_status", "", GAUGE, 2, "gpumon_throttle_status", "Active clock throttle reasons (bitset: 1 power, 2 thermal, 4 HBM thermal, 8 VR thermal, 16 PROCHOT, 32 low utilization, 64 host limit).", nullptr, 0},
     {GM_FI_PERF_LEVEL,            I64, SRC_PERF,      "perf_level", "", 0, 0, nullptr, nullptr, nullptr, 0},
     {GM_FI_FAN_SPEED,             I64, SRC_METRICS,   "fan_speed", "%", 0, 0, nullptr, nullptr, nullptr, 0},

@@ -256,6 +256,13 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
       if (!ps.empty()) w.raw(ps.data(), ps.size() * sizeof(gm_process_t));
       return w.data();
     }
+    case OP_PROCESS_SOURCE: {
+      uint32_t gpu = r.u32();
+      std::string src;
+      w.i32(engine_->process_source(gpu, &src));
+      w.str(src);
+      return w.data();
+    }
     case OP_DEVICE_MODE: {
       uint32_t gpu = r.u32();
       gm_device_mode_t m;

@@ -177,8 +177,10 @@ enum {
   GM_FI_SYNC_BOOST_VIOLATION = 242,  /* no AMD meaning: never supported */
   GM_FI_BOARD_LIMIT_VIOLATION = 243, /* us: PROCHOT + VR thermal */
   GM_FI_LOW_UTIL_VIOLATION = 244,
-  GM_FI_RELIABILITY_VIOLATION = 245, /* gfx clock below host limit */
+  GM_FI_RELIABILITY_VIOLATION = 245, /* no AMD counterpart: blank on real devices (see GM_FI_GFX_BELOW_HOST_LIMIT) */
   GM_FI_THROTTLE_STATUS = 246,       /* bitset, see GM_THROTTLE_* */
+  GM_FI_GFX_BELOW_HOST_LIMIT = 247,  /* us the shader clock spent under the limit the host set, whatever the cause:
+                                        an idle GPU accrues it at wall-clock rate, so it is no "violation" */
   GM_FI_PERF_LEVEL = 190,            /* P-state analog: DPM level, 0 = highest */
   GM_FI_FAN_SPEED = 191,             /* % (OAM modules: not supported) */
 
@@ -484,17 +486,29 @@ enum {
  * field group on every call, bindings/go/dcgm/device_status.go:115-180). */
 GM_API gm_status_t gm_device_status(uint32_t gpu, gm_device_status_t* out);
 
-/* Processes currently holding the GPU (direct device query, not accounting). */
+/* Processes currently holding the GPU (direct device query, not accounting).  The list comes from the device
+ * library's process table where the host has one (source "kfd"); else from the kernel's per-file DRM statistics
+ * under /proc/<pid>/fdinfo ("fdinfo": memory and engine time of every process the caller may look into); else
+ * from the open render-node descriptors under /proc/<pid>/fd ("open-files": who holds the card, without figures:
+ * vram_bytes and gtt_bytes are then GM_PROC_MEM_UNKNOWN). */
+#define GM_PROC_MEM_UNKNOWN (~0ull)
 typedef struct {
   uint32_t pid;
   uint32_t type; /* 0 = compute, 1 = graphics, 2 = both */
-  uint64_t vram_bytes;
+  uint64_t vram_bytes; /* GM_PROC_MEM_UNKNOWN = not known */
   uint64_t gtt_bytes;
   uint64_t gfx_engine_ns;  /* cumulative gfx engine time */
   uint32_t cu_occupancy;   /* CUs currently occupied; 0xffffffff = blank */
   char name[GM_STR_LEN];
 } gm_process_t;
 GM_API gm_status_t gm_device_processes(uint32_t gpu, gm_process_t* out, int* n);
+/* Which source answers gm_device_processes for this GPU on this host: "kfd", "fdinfo", "open-files", "fake" or
+ * "none" (then gm_device_processes reports NOT_SUPPORTED or NO_PERMISSION). */
+GM_API gm_status_t gm_process_source(uint32_t gpu, char* buf, size_t cap);
+/* The /proc walk on its own (no engine, no device library): users of the card at `pci_bdf` / render node
+ * `render_minor` under `proc_root` ("/proc").  *n: capacity on entry, count on return; `source` as above. */
+GM_API gm_status_t gm_proc_scan(const char* proc_root, const char* pci_bdf, int render_minor, gm_process_t* out, int* n,
+                                char* source, size_t cap);
 
 typedef struct {
   uint32_t version;
@@ -736,8 +750,13 @@ typedef struct {
   const char* state_path;   /* NULL = none; file that carries what the exporter itself accumulates (the
                                gpu_last_not_idle_time latch, per GPU UUID) across restarts */
   int32_t health;           /* run the engine's health check on every sweep: gpumon_health_* families */
+  int32_t slow_interval_ms; /* 0 = 1000.  Sources that cost a device-library call each and change slowly (error counters,
+                               bad pages, performance level / power cap, memory usage) keep this period when
+                               interval_ms is shorter */
+  int32_t pod_refresh_ms;   /* 0 = 10000.  Period of the pod-map query (kubelet or file), on a thread of its own over
+                               one kept connection: a kubelet that does not answer never delays a sweep */
 } gm_exporter_config_t;
-#define GM_EXPORTER_CONFIG_VERSION GM_VERSION(gm_exporter_config_t, 4)
+#define GM_EXPORTER_CONFIG_VERSION GM_VERSION(gm_exporter_config_t, 5)
 
 typedef uint32_t gm_exporter_t;
 GM_API gm_status_t gm_exporter_create(const gm_exporter_config_t* cfg, gm_exporter_t* out);

@@ -55,7 +55,7 @@ FI = dict(
     VRAM_USED=252, ECC_CE_VOLATILE=310, ECC_UE_VOLATILE=311, ECC_UMC_UE=321, BAD_PAGES_CE=390,
     BAD_PAGES_UE=391, BAD_PAGES_PENDING=392, XGMI_CRC_ERRORS=409, XGMI_DATA_ERRORS=419,
     XGMI_BANDWIDTH_TOTAL=449, XGMI_LINK_STATUS_0=470, XGMI_LINKS_DOWN=481, XGMI_ERROR_STATUS=482,
-    PROF_GR_ENGINE_ACTIVE=1001, PROF_CU_ACTIVE=1002, PROF_MFMA_ACTIVE=1004, PROF_MEM_PIPE_ACTIVE=1020, LOW_UTIL_VIOLATION=244, RELIABILITY_VIOLATION=245, THROTTLE_STATUS=246, ECC_DEFERRED=314,
+    PROF_GR_ENGINE_ACTIVE=1001, PROF_CU_ACTIVE=1002, PROF_MFMA_ACTIVE=1004, PROF_MEM_PIPE_ACTIVE=1020, LOW_UTIL_VIOLATION=244, RELIABILITY_VIOLATION=245, THROTTLE_STATUS=246, GFX_BELOW_HOST_LIMIT=247, ECC_DEFERRED=314,
 )
 THROTTLE = dict(POWER=1, THERMAL=2, HBM_THERMAL=4, VR_THERMAL=8, PROCHOT=16, LOW_UTIL=32, HOST_LIMIT=64)
 
@@ -261,8 +261,8 @@ class ExporterConfig(C.Structure):
                 ("output_path", C.c_char_p), ("listen", C.c_char_p), ("kubelet_socket", C.c_char_p),
                 ("resource_names", C.c_char_p), ("pod_map_path", C.c_char_p), ("rest_api", C.c_int32),
                 ("legacy_layout", C.c_int32), ("diag_results_path", C.c_char_p), ("state_path", C.c_char_p),
-                ("health", C.c_int32)]
-    VERSION = 4
+                ("health", C.c_int32), ("slow_interval_ms", C.c_int32), ("pod_refresh_ms", C.c_int32)]
+    VERSION = 5
 
 
 class PodExporterConfig(C.Structure):

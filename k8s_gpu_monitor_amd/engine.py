@@ -110,6 +110,24 @@ def device_processes(gpu):
     return [_struct_dict(buf[i], skip=()) for i in range(n.value)]
 
 
+def process_source(gpu):
+    """Where device_processes gets its list on this host: "kfd", "fdinfo", "open-files", "fake" or "none"."""
+    buf = C.create_string_buffer(32)
+    check(lib().gm_process_source(gpu, buf, C.c_size_t(32)))
+    return buf.value.decode()
+
+
+def proc_scan(proc_root="/proc", pci_bdf="", render_minor=-1):
+    """The /proc walk on its own: (source, [process dict]) for the card at pci_bdf / render node render_minor."""
+    buf = (A.Process * A.GM_MAX_PROCS)()
+    n = C.c_int(A.GM_MAX_PROCS)
+    src = C.create_string_buffer(32)
+    L = lib()
+    L.gm_proc_scan.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(A.Process), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    check(L.gm_proc_scan(_b(proc_root), _b(pci_bdf), render_minor, buf, C.byref(n), src, 32))
+    return src.value.decode(), [_struct_dict(buf[i], skip=()) for i in range(n.value)]
+
+
 def device_mode(gpu):
     m = A.versioned(A.DeviceMode)
     check(lib().gm_device_mode(gpu, C.byref(m)))
@@ -404,9 +422,11 @@ class EventSet:
 class Exporter:
     def __init__(self, interval_ms=1000, gpus=None, output_path=None, listen=None, profiling=False, extras=False,
                  self_metrics=False, rest_api=False, legacy_layout=False, kubelet_socket=None, pod_map_path=None,
-                 resource_names=None, diag_results_path=None, state_path=None, health=False):
+                 resource_names=None, diag_results_path=None, state_path=None, health=False, slow_interval_ms=0,
+                 pod_refresh_ms=0):
         c = A.versioned(A.ExporterConfig)
         c.interval_ms = interval_ms
+        c.slow_interval_ms, c.pod_refresh_ms = slow_interval_ms, pod_refresh_ms
         c.profiling, c.amd_extras, c.self_metrics = int(profiling), int(extras), int(self_metrics)
         c.rest_api, c.legacy_layout, c.health = int(rest_api), int(legacy_layout), int(health)
         self._keep = [_b(x) for x in (gpus, output_path, listen, kubelet_socket, resource_names, pod_map_path,

@@ -66,7 +66,7 @@ class Device:
             if e.status in (A.GM_ST_NOT_SUPPORTED, A.GM_ST_NO_PERMISSION):
                 return []
             raise
-        return [ProcessInfo(p["pid"], p["name"], p["vram_bytes"] >> 20, "C") for p in procs]
+        return [ProcessInfo(p["pid"], p["name"], _mib(p["vram_bytes"]), "C") for p in procs]
 
     @property
     def gfx_version(self):
@@ -161,10 +161,18 @@ def new_device(index: int, lite: bool = False, api=E) -> Device:
     return dev
 
 
+A_PROC_MEM_UNKNOWN = 0xFFFFFFFFFFFFFFFF
+
+
+def _mib(vram_bytes):
+    """MiB, or None for a process that is only known to hold the device open (GM_PROC_MEM_UNKNOWN)."""
+    return None if vram_bytes == A_PROC_MEM_UNKNOWN else vram_bytes >> 20
+
+
 def device_status(index: int, api=E) -> DeviceStatus:
     s = api.device_status(index)
     kb_to_mb = lambda x: None if x is None else x // 1000  # noqa: E731
-    procs = [ProcessInfo(p["pid"], p["name"], p["vram_bytes"] >> 20, "C") for p in api.device_processes(index)]
+    procs = [ProcessInfo(p["pid"], p["name"], _mib(p["vram_bytes"]), "C") for p in api.device_processes(index)]
     return DeviceStatus(
         power=None if s["power_w"] is None else int(s["power_w"]), temperature=s["temperature_c"],
         utilization=UtilizationInfo(s["gfx_util"], s["mem_util"], s["enc_util"], s["dec_util"]),

@@ -500,3 +500,34 @@ def test_health_families_follow_the_engine_health_check(engine2):
     with E.Exporter() as ex:  # off by default: the contract output is unchanged
         ex.sweep()
         assert "gpumon_health_status" not in parse(ex.render())
+
+
+def test_slow_sources_keep_their_own_period_under_a_fast_collection_interval():
+    """At -d 100 the bulk metrics are read ten times a second, but the sources that cost a device-library call each and
+    move slowly (error counters, bad pages, performance level, memory usage) keep a one-second period: that is what
+    makes a 100 ms exporter on eight GPUs cost little more than the bulk read.  Seen from outside as the sample
+    timestamps of one field of each kind."""
+    import time
+    from k8s_gpu_monitor_amd import abi as A
+    E.init(backend="fake", backend_spec="gpus=2,seed=3")
+    try:
+        with E.Exporter(interval_ms=100, slow_interval_ms=1000) as ex:
+            ex.start()
+            seen = {A.FI["GPU_TEMP"]: set(), A.FI["ECC_CE_VOLATILE"]: set(), A.FI["VRAM_USED"]: set(), A.FI["BAD_PAGES_UE"]: set()}
+            t_end = time.time() + 1.6
+            while time.time() < t_end:
+                for f, stamps in seen.items():
+                    stamps.update(ts for ts, _v in E.values_since(0, f, 0))
+                time.sleep(0.03)
+            ex.stop()
+            assert len(seen[A.FI["GPU_TEMP"]]) >= 12, {k: len(v) for k, v in seen.items()}
+            for f in (A.FI["ECC_CE_VOLATILE"], A.FI["VRAM_USED"], A.FI["BAD_PAGES_UE"]):
+                assert 1 <= len(seen[f]) <= 3, {k: len(v) for k, v in seen.items()}
+            text = ex.render()          # and everything is still exported
+            assert "dcgm_ecc_sbe_volatile_total" in text and "dcgm_fb_used" in text and "dcgm_gpu_temp" in text
+        # a collection interval at or above the slow period: one schedule, as before
+        with E.Exporter(interval_ms=1000) as ex:
+            ex.sweep()
+            assert "dcgm_ecc_sbe_volatile_total" in ex.render()
+    finally:
+        E.shutdown()

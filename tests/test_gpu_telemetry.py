@@ -167,18 +167,39 @@ def test_sampling_overhead_is_small(hw):
 
 
 def test_own_process_is_attributed(hw):
+    """This process holds 1 GiB on the GPU and must show up in the GPU's process list, whichever source the host
+    offers: the device library's table ("kfd") and the kernel's per-file DRM statistics ("fdinfo") also say how much
+    memory it holds; where the kernel writes neither, the holders of the render node are listed without figures
+    ("open-files").  `gpumon ps` prints the same list."""
+    import subprocess
+    from conftest import bin_path
     gpu = _engine_index_of_hip0()
     keep = torch.ones(1 << 28, device="cuda:0")  # 1 GiB
     torch.cuda.synchronize()
-    try:
-        procs = E.device_processes(gpu)
-    except E.GpumonError as e:
-        assert e.status in (A.GM_ST_NOT_SUPPORTED, A.GM_ST_NO_PERMISSION), e
-        pytest.skip("the driver exposes no per-process table to this user (reported as such, not as an empty list)")
-    if not procs:
-        pytest.skip("the process table is readable but empty")
+    src = E.process_source(gpu)
+    assert src in ("kfd", "fdinfo", "open-files"), src
+    procs = E.device_processes(gpu)
     mine = [p for p in procs if p["pid"] == os.getpid()]
-    assert mine and mine[0]["vram_bytes"] >= 1 << 30
+    assert mine, (src, procs)
+    assert mine[0]["name"].startswith("python") or mine[0]["name"].startswith("pytest"), mine
+    if src == "open-files":
+        # the keys this kernel does write for the render node, for the record of what the fallback had to work with
+        keys = set()
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                if "/dev/dri/" in os.readlink(f"/proc/self/fd/{fd}"):
+                    keys |= {l.split(":")[0] for l in open(f"/proc/self/fdinfo/{fd}").read().splitlines() if ":" in l}
+            except OSError:
+                pass
+        print("fdinfo keys of the render node on this host:", sorted(keys))
+        assert not any(k.startswith("drm-") for k in keys), keys
+        assert mine[0]["vram_bytes"] == 0xFFFFFFFFFFFFFFFF
+    else:
+        assert 1 << 30 <= mine[0]["vram_bytes"] < 1 << 40
+    r = subprocess.run([bin_path("gpumon"), "ps", "-c", "1"], capture_output=True, text=True, timeout=60,
+                       env=dict(os.environ, GPUMON_BACKEND="amdsmi"))
+    assert r.returncode == 0 and f"process list from {src}" in r.stdout, r.stdout + r.stderr
+    assert any(line.split()[1:2] == [str(os.getpid())] for line in r.stdout.splitlines() if not line.startswith("#")), r.stdout
     del keep
 
 

@@ -230,6 +230,54 @@ def test_exporter_attaches_pod_labels_from_kubelet(tmp_path):
         E.shutdown()
 
 
+def test_a_kubelet_that_does_not_answer_never_holds_up_a_sweep(tmp_path):
+    """The pod map has a thread and a kept connection of its own (the reference dials the kubelet once a second on the
+    path that publishes: src/watchers.go:41 -> kubelet_server.go:36-41).  With a kubelet that takes 3 s per answer the
+    file is still published every interval, the labels arrive when the answer does, and all queries share one
+    connection; when the kubelet restarts, the next query opens a second one."""
+    E.init(backend="fake", backend_spec="gpus=2,seed=1")
+    try:
+        uuid0 = E.device_attributes(0)["uuid"]
+        pods = [("job", "team", [("c", [("amd.com/gpu", [uuid0])])])]
+        k = FakeKubelet(str(tmp_path / "k.sock"), pods)
+        out = tmp_path / "m.prom"
+        ex = E.Exporter(kubelet_socket=k.path, output_path=str(out), interval_ms=100, pod_refresh_ms=300, self_metrics=True)
+        try:
+            assert len(k.calls) == 1                      # the start-up query, answered at once
+            k.delay = 3.0
+            ex.start()
+            stamps = set()
+            t_end = time.time() + 2.0
+            while time.time() < t_end:
+                if out.exists():
+                    stamps.add(out.stat().st_mtime_ns)
+                time.sleep(0.02)
+            assert len(stamps) >= 12, len(stamps)         # 20 sweeps due in 2 s; a blocked loop would show 1 or 2
+            assert len(k.calls) == 2                      # one query in flight the whole time
+            k.delay = 0.0
+            time.sleep(2.2)                               # the slow answer arrives, quick ones follow
+            text = out.read_text()
+            assert 'pod_name="job"' in text
+            fam = promparse.parse(text)
+            assert fam["gpumon_exporter_kubelet_connects_total"].samples[0][1] == 1
+            assert fam["gpumon_exporter_pod_map_refreshes_total"].samples[0][1] >= 4
+            assert fam["gpumon_exporter_pod_map_up"].samples[0][1] == 1
+            # kubelet restart: the kept connection is dead, the next query replaces it without losing the map
+            k.stop()
+            time.sleep(0.5)
+            k = FakeKubelet(k.path, pods)
+            time.sleep(1.0)
+            fam = promparse.parse(out.read_text())
+            assert fam["gpumon_exporter_kubelet_connects_total"].samples[0][1] >= 2
+            assert fam["gpumon_exporter_pod_map_up"].samples[0][1] == 1 and 'pod_name="job"' in out.read_text()
+        finally:
+            ex.stop()
+            ex.close()
+            k.stop()
+    finally:
+        E.shutdown()
+
+
 def test_exporter_checkpoint_file_fallback(tmp_path):
     E.init(backend="fake", backend_spec="gpus=2,seed=1")
     try:

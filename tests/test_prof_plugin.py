@@ -109,6 +109,10 @@ def test_child_mode_exports_what_the_probe_measured_and_blanks_the_rest(tmp_path
         tensor = {l["gpu"]: v for l, v in fam["dcgm_fi_prof_pipe_tensor_active"].samples}
         sm = {l["gpu"]: v for l, v in fam["dcgm_fi_prof_sm_active"].samples}
         assert tensor == {"0": 42.5} and sm == {"0": 77.25}, (tensor, sm)
+        # the values are duty-cycle samples, and the HELP text of exactly the counter-fed families says so
+        assert fam["dcgm_fi_prof_pipe_tensor_active"].help.endswith("Sampled: about 0.75 s of counting every 1 s.")
+        assert fam["dcgm_fi_prof_sm_active"].help.endswith("every 1 s.")
+        assert "Sampled" not in fam["dcgm_fi_prof_gr_engine_active"].help
         assert "gpumon_prof_mem_pipe_active" not in fam or not fam["gpumon_prof_mem_pipe_active"].samples
         assert len(fam["dcgm_fi_prof_gr_engine_active"].samples) == 2  # not counter-derived on this backend
         time.sleep(2.5)
