@@ -4,7 +4,7 @@
 //
 //   gpumon-diag info                       HIP-side device facts
 //   gpumon-diag hbm    [-g GPU | --gpus LIST|all] [--bytes N] [--iters N] [--kernel NAME|all] [--min-tbps X]
-//   gpumon-diag memtest[-g GPU | --gpus LIST|all] [--bytes N | --fraction F] [--patterns a,b] [--passes N]
+//   gpumon-diag memtest[-g GPU | --gpus LIST|all] [--bytes N | --fraction F] [--patterns a,b] [--passes N] [--march]
 //   gpumon-diag mfma   [-g GPU | --gpus LIST|all] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]
 //   gpumon-diag gemm   [-g GPU | --gpus LIST|all] [--dtype bf16|fp8|mxfp8] [--m M --n N --k K] [--seconds S] [--check-every N]
 //   gpumon-diag rccl   [--gpus 0,1,..] [--ops a,b] [--min-bytes N] [--max-bytes N] [--scaling] [--min-busbw X]
@@ -449,6 +449,7 @@ int cmd_memtest(const Args& a, Report& r, int gpu) {
   c.fraction = a.num("--fraction", 0.90);
   c.chunk_bytes = a.size("--chunk", 0);
   c.passes = (uint32_t)a.num("--passes", 1);
+  c.march = a.has("--march") ? 1 : 0;
   if (a.has("--patterns"))
     for (auto& p : csv(a.str("--patterns"))) {
       bool ok = false;
@@ -464,25 +465,36 @@ int cmd_memtest(const Args& a, Report& r, int gpu) {
   c.progress_user = &quiet;
   gmd_memtest_result_t m;
   DIAG_CALL(r, gmd_memtest(gpu, &c, &m));
-  r.text("memtest on GPU %d: %.1f GiB in %u chunks, %u patterns, %.2f s\n  write %.2f TB/s  verify %.2f TB/s  errors %llu\n", gpu,
+  r.text("memtest on GPU %d: %.1f GiB in %u chunks, %u patterns, %.2f s\n  write %.2f TB/s  verify %.2f TB/s  errors %llu%s\n", gpu,
          m.bytes_tested / 1073741824.0, m.chunks, m.patterns_run, m.seconds, m.write_tbps, m.verify_tbps,
-         (unsigned long long)m.errors);
+         (unsigned long long)m.errors, m.scrubbed ? "" : "  (no memory left for the cache scrub: the last lines written may have been checked in the cache)");
+  if (m.march_passes) r.text("  march (check + write complement, up and down): %.2f TB/s read + written\n", m.march_tbps);
   std::string log = "[";
   for (uint32_t i = 0; i < m.logged; i++) {
-    r.text("  offset 0x%llx pattern 0x%x expected %016llx got %016llx\n", (unsigned long long)m.log[i].byte_offset,
-           m.log[i].pattern, (unsigned long long)m.log[i].expected, (unsigned long long)m.log[i].actual);
+    r.text("  offset 0x%llx (chunk %u, address 0x%llx, +0x%03x in its 4 KiB page) pattern 0x%x expected %016llx got %016llx: %u bit%s\n",
+           (unsigned long long)m.log[i].byte_offset, m.log[i].chunk, (unsigned long long)m.log[i].device_address, m.log[i].page_offset,
+           m.log[i].pattern, (unsigned long long)m.log[i].expected, (unsigned long long)m.log[i].actual, m.log[i].flipped_bits,
+           m.log[i].flipped_bits == 1 ? "" : "s");
     log += std::string(i ? "," : "") + "{\"offset\":" + std::to_string(m.log[i].byte_offset) + ",\"pattern\":" +
-           std::to_string(m.log[i].pattern) + "}";
+           std::to_string(m.log[i].pattern) + ",\"chunk\":" + std::to_string(m.log[i].chunk) + ",\"device_address\":" +
+           std::to_string(m.log[i].device_address) + ",\"page_offset\":" + std::to_string(m.log[i].page_offset) + ",\"flipped_bits\":" +
+           std::to_string(m.log[i].flipped_bits) + "}";
   }
   r.member("memtest", "{\"bytes_tested\":" + std::to_string(m.bytes_tested) + ",\"errors\":" + std::to_string(m.errors) +
                           ",\"patterns\":" + std::to_string(m.patterns_run) + ",\"write_tbps\":" + jnum(m.write_tbps) +
-                          ",\"verify_tbps\":" + jnum(m.verify_tbps) + ",\"seconds\":" + jnum(m.seconds) + ",\"log\":" + log + "]}");
+                          ",\"verify_tbps\":" + jnum(m.verify_tbps) + ",\"march_passes\":" + std::to_string(m.march_passes) + ",\"march_tbps\":" +
+                          jnum(m.march_tbps) + ",\"scrubbed\":" + (m.scrubbed ? "true" : "false") + ",\"seconds\":" + jnum(m.seconds) +
+                          ",\"log\":" + log + "]}");
   if (m.errors) r.verdict_fail("memtest", GM_HEALTH_WATCH_MEM, (double)m.errors, "memtest found %llu bad words in %.1f GiB", (unsigned long long)m.errors, m.bytes_tested / 1073741824.0);
   // rates: only where the region is large enough for launch costs and the cache not to decide
   if (m.bytes_tested >= (4ull << 30)) {
     r.metrics["memtest.write"] = m.write_tbps, r.metrics["memtest.verify"] = m.verify_tbps;
     r.grade("memtest", GM_HEALTH_WATCH_MEM, "memtest write pass", m.write_tbps, e.want("memtest.write"), e, "TB/s");
     r.grade("memtest", GM_HEALTH_WATCH_MEM, "memtest verify pass", m.verify_tbps, e.want("memtest.verify"), e, "TB/s");
+    if (m.march_passes) {
+      r.metrics["memtest.march"] = m.march_tbps;
+      r.grade("memtest", GM_HEALTH_WATCH_MEM, "memtest march", m.march_tbps, e.want("memtest.march"), e, "TB/s");
+    }
   }
   r.verdict_pass("memtest", GM_HEALTH_WATCH_MEM, 0, "no bad words");
   return 0;
@@ -1329,6 +1341,7 @@ int cmd_run(const Args& a, Report& r, const std::vector<int>& gpus, MfmaWatch* m
   if ((rc = run_on(sub, r, gpus, [](const Args& x, Report& y, int g) { return cmd_hbm(x, y, g); }))) return rc;
   if (level < 3) sub.kv["--bytes"] = level == 1 ? "1G" : "16G";
   else sub.kv.erase("--bytes");
+  if (level >= 2) sub.kv["--march"] = "1";
   if ((rc = run_on(sub, r, gpus, [](const Args& x, Report& y, int g) { return cmd_memtest(x, y, g); }))) return rc;
   if (level >= 2) {
     sub.kv["--seconds"] = "1";
@@ -1360,7 +1373,7 @@ void usage() {
           "usage: gpumon-diag <info|expect|hbm|memtest|mfma|gemm|rccl|links|run> [options] [--json] [--publish FILE]\n"
           "  --publish FILE leaves the JSON report where `gpumon-exporter --diag-results` picks it up\n"
           "  hbm     [-g GPU | --gpus LIST|all] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
-          "  memtest [-g GPU | --gpus LIST|all] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N]\n"
+          "  memtest [-g GPU | --gpus LIST|all] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N] [--march]\n"
           "  mfma    [-g GPU | --gpus LIST|all] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
           "  gemm    [-g GPU | --gpus LIST|all] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--check-every N] [--min-tflops X]\n"
           "          [--no-telemetry] [--mfma-counters]\n"

@@ -63,6 +63,24 @@ int main(int argc, char** argv) {
       return 1;
     }
     fclose(f);
+    // A pid file outlives its process, and pids are reused: only a process that is a host engine is signalled.
+    {
+      char path[64], comm[64] = "";
+      snprintf(path, sizeof path, "/proc/%ld/comm", pid);
+      FILE* c = fopen(path, "r");
+      if (!c || !fgets(comm, sizeof comm, c)) {
+        fprintf(stderr, "no running host engine found (pid %ld of %s is gone)\n", pid, pid_file.c_str());
+        if (c) fclose(c);
+        return 1;
+      }
+      fclose(c);
+      comm[strcspn(comm, "\n")] = 0;
+      // the kernel keeps 15 characters of the name: "gpumon-hostengi"
+      if (strncmp(comm, "gpumon-hostengine", 15) != 0) {
+        fprintf(stderr, "pid %ld (%s) is not a host engine: %s is stale, nothing signalled\n", pid, comm, pid_file.c_str());
+        return 1;
+      }
+    }
     if (kill((pid_t)pid, SIGTERM) != 0) {
       perror("kill");
       return 1;

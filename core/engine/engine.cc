@@ -6,6 +6,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstring>
 #include <unistd.h>
@@ -833,13 +834,20 @@ gm_status_t LocalEngine::event_subscribe(EventFn fn, uint32_t* sub) {
       ensure_internal_watch("ras", all, {GM_FI_ECC_UE_VOLATILE, GM_FI_ECC_DEFERRED}, GM_DEFAULT_UPDATE_FREQ_US);
     }
   }
-  return update_all(true);  // the totals seen now are the baseline: only later errors are events
+  // The totals seen now are the baseline: only later errors are events.  Best effort: the subscription stands
+  // whether or not this cycle could run (an engine that is not sampling yet takes its baseline with its first cycle),
+  // so the caller is never told "failed" about a callback that stays registered.
+  gm_status_t st = update_all(true);
+  if (st != GM_ST_OK) GM_LOGI("event subscription %u: baseline sample not taken (%s)", *sub, status_string(st));
+  return GM_ST_OK;
 }
 
 gm_status_t LocalEngine::event_unsubscribe(uint32_t sub) {
   {
     std::lock_guard<std::mutex> l(state_mu_);
     if (!event_subs_.erase(sub)) return GM_ST_NOT_FOUND;
+    // nobody listens any more: the error totals need not be sampled on the listeners' account
+    if (event_subs_.empty() && internal_watches_.erase("ras")) rebuild_watch_table();
   }
   notifier_.drain();  // no callback of this subscription runs after we return
   return GM_ST_OK;
@@ -878,6 +886,9 @@ gm_status_t LocalEngine::diag_submit(const gm_diag_result_t& r) {
     return GM_ST_BADPARAM;
   if (r.health != GM_HEALTH_PASS && r.health != GM_HEALTH_WARN && r.health != GM_HEALTH_FAIL) return GM_ST_BADPARAM;
   if (!r.system || (r.system & (r.system - 1)) || !(r.system & GM_HEALTH_WATCH_ALL)) return GM_ST_BADPARAM;  // exactly one system
+  // Test names go into label values, JSON and fixed-size reply arrays: a plain identifier, and a bounded number of them.
+  for (const char* c = r.test; *c; c++)
+    if (!isalnum((unsigned char)*c) && *c != '_' && *c != '.' && *c != '-') return GM_ST_BADPARAM;
   gm_diag_result_t kept = r;
   if (!kept.ts_us) kept.ts_us = now_us();
   GpuState& g = *gpus_[r.gpu];
@@ -885,6 +896,7 @@ gm_status_t LocalEngine::diag_submit(const gm_diag_result_t& r) {
   {
     std::lock_guard<std::mutex> l(g.hist_mu);
     auto it = g.diag.find(kept.test);
+    if (it == g.diag.end() && g.diag.size() >= GM_MAX_DIAG_TESTS) return GM_ST_INSUFFICIENT_SIZE;
     // The same verdict handed in again (a report file read twice) is not a second failure.
     news = it == g.diag.end() || it->second.ts_us != kept.ts_us || it->second.health != kept.health;
     g.diag[kept.test] = kept;

@@ -39,30 +39,60 @@ static void set_nonblock(int fd) {
 }
 
 bool HttpServer::start(const std::string& address, HttpHandler handler, int timeout_ms) {
+  // "host:port", ":port", "port"; an IPv6 host in brackets: "[::1]:9400", "[::]:9400" (both families where the
+  // host allows dual-stack sockets).
   std::string host = "0.0.0.0", port = address;
-  size_t c = address.rfind(':');
-  if (c != std::string::npos) {
-    if (c > 0) host = address.substr(0, c);
-    port = address.substr(c + 1);
+  bool v6 = false;
+  if (!address.empty() && address[0] == '[') {
+    const size_t close_br = address.find(']');
+    if (close_br == std::string::npos) {
+      GM_LOGE("http: malformed listen address %s", address.c_str());
+      return false;
+    }
+    host = address.substr(1, close_br - 1);
+    port = close_br + 1 < address.size() && address[close_br + 1] == ':' ? address.substr(close_br + 2) : "0";
+    v6 = true;
+  } else {
+    size_t c = address.rfind(':');
+    if (c != std::string::npos) {
+      if (c > 0) host = address.substr(0, c);
+      port = address.substr(c + 1);
+    }
   }
   if (host == "localhost") host = "127.0.0.1";
-  int fd = socket(AF_INET, SOCK_STREAM, 0);
-  if (fd < 0) return false;
+  int fd = socket(v6 ? AF_INET6 : AF_INET, SOCK_STREAM, 0);
+  if (fd < 0) {
+    GM_LOGE("http: cannot open a socket for %s: %s", address.c_str(), strerror(errno));
+    return false;
+  }
   int one = 1;
   setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-  sockaddr_in sa;
-  memset(&sa, 0, sizeof sa);
-  sa.sin_family = AF_INET;
-  sa.sin_port = htons((uint16_t)atoi(port.c_str()));
-  if (inet_pton(AF_INET, host.c_str(), &sa.sin_addr) != 1) sa.sin_addr.s_addr = htonl(INADDR_ANY);
-  if (bind(fd, (sockaddr*)&sa, sizeof sa) != 0 || listen(fd, 128) != 0) {
+  sockaddr_storage ss;
+  memset(&ss, 0, sizeof ss);
+  socklen_t sl;
+  if (v6) {
+    sockaddr_in6* sa = (sockaddr_in6*)&ss;
+    sa->sin6_family = AF_INET6;
+    sa->sin6_port = htons((uint16_t)atoi(port.c_str()));
+    if (inet_pton(AF_INET6, host.c_str(), &sa->sin6_addr) != 1) sa->sin6_addr = in6addr_any;
+    int off = 0;  // the wildcard address takes IPv4 clients too
+    setsockopt(fd, IPPROTO_IPV6, IPV6_V6ONLY, &off, sizeof off);
+    sl = sizeof *sa;
+  } else {
+    sockaddr_in* sa = (sockaddr_in*)&ss;
+    sa->sin_family = AF_INET;
+    sa->sin_port = htons((uint16_t)atoi(port.c_str()));
+    if (inet_pton(AF_INET, host.c_str(), &sa->sin_addr) != 1) sa->sin_addr.s_addr = htonl(INADDR_ANY);
+    sl = sizeof *sa;
+  }
+  if (bind(fd, (sockaddr*)&ss, sl) != 0 || listen(fd, 128) != 0) {
     GM_LOGE("http: cannot listen on %s: %s", address.c_str(), strerror(errno));
     close(fd);
     return false;
   }
-  socklen_t sl = sizeof sa;
-  getsockname(fd, (sockaddr*)&sa, &sl);
-  port_ = ntohs(sa.sin_port);
+  sl = sizeof ss;
+  getsockname(fd, (sockaddr*)&ss, &sl);
+  port_ = ntohs(v6 ? ((sockaddr_in6*)&ss)->sin6_port : ((sockaddr_in*)&ss)->sin_port);
   set_nonblock(fd);
   int p[2];
   if (pipe(p) != 0) {

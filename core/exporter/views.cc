@@ -476,7 +476,12 @@ gm_status_t view_diag_results(Engine* e, uint32_t gpu, bool json, std::string* o
         if (*c == '"' || *c == '\\') msg += '\\';
         msg += (unsigned char)*c < 0x20 ? ' ' : *c;
       }
-      s += std::string(i ? "," : "") + "{\"test\":\"" + r.test + "\",\"system\":\"" + health_system_name(r.system) + "\",\"health\":\"" +
+      std::string test;
+      for (const char* c = r.test; *c; c++) {
+        if (*c == '"' || *c == '\\') test += '\\';
+        test += (unsigned char)*c < 0x20 ? ' ' : *c;
+      }
+      s += std::string(i ? "," : "") + "{\"test\":\"" + test + "\",\"system\":\"" + health_system_name(r.system) + "\",\"health\":\"" +
            health_result_name(r.health) + "\",\"value\":" + (std::isnan(r.value) ? std::string("null") : strprintf("%.6g", r.value)) +
            ",\"time\":\"" + format_time_us(r.ts_us) + "\",\"message\":\"" + msg + "\"}";
     }

@@ -10,8 +10,20 @@
 // pass every workgroup walks its own contiguous span (128 workgroups per CU).  The
 // pattern is a template parameter, so the kernels are loads / stores plus a few
 // integer ops.  Mismatches are counted with one atomic per mismatching lane
-// (rare) and the first few are logged with offset, expected and actual value so
-// a failing HBM stack / channel can be located.
+// (rare) and the first few are logged with the offset in the region, the chunk, the
+// device virtual address, its offset in the 4 KiB page (the granule in which
+// consecutive addresses change HBM channel), the expected and the actual value and
+// the number of bits that differ: the operator's starting point for mapping a fault
+// to a stack or channel (the physical mapping itself is not visible to a process).
+//
+// Between the write and the verify pass a scrub buffer of twice the 256 MiB
+// Infinity Cache is overwritten, so that the lines written last have been pushed
+// out to the DRAM cells before they are read back: the cache sits in front of the
+// memory, and a test that reads its own tail out of it has not tested that memory.
+//
+// A march pass (optional) reads every word, checks it and writes its complement in
+// one kernel, up and then down again: each cell is read after having held a value
+// and its inverse, and the kernel is a read+write stress at the same time.
 //
 // The region is allocated in chunks (default 2 GiB) so a fragmented heap still
 // yields high coverage; allocation stops at the first failure and the achieved
@@ -74,7 +86,7 @@ struct VerifyOut {
   gmd_memtest_error_t log[GMD_MEMTEST_LOG];
 };
 
-__device__ __forceinline__ void report(VerifyOut* out, uint64_t word, uint64_t expect, uint64_t got, uint32_t pattern) {
+__device__ __forceinline__ void report(VerifyOut* out, uint64_t word, uint64_t expect, uint64_t got, uint32_t pattern, const void* where) {
   atomicAdd(&out->errors, 1ull);
   unsigned slot = atomicAdd(&out->logged, 1u);
   if (slot < GMD_MEMTEST_LOG) {
@@ -83,10 +95,20 @@ __device__ __forceinline__ void report(VerifyOut* out, uint64_t word, uint64_t e
     out->log[slot].actual = got;
     out->log[slot].pattern = pattern;
     out->log[slot].chunk = 0;
+    out->log[slot].device_address = (uint64_t)where;
+    out->log[slot].flipped_bits = (uint32_t)__popcll(expect ^ got);
+    out->log[slot].page_offset = (uint32_t)((uint64_t)where & 4095);
   }
 }
 
-template <uint32_t PAT>
+// INV: the region holds the complement of the pattern (second half of a march).
+template <uint32_t PAT, bool INV>
+__device__ __forceinline__ uint64_t want_word(uint64_t w, uint64_t seed) {
+  const uint64_t e = expected_word(PAT, w, seed);
+  return INV ? ~e : e;
+}
+
+template <uint32_t PAT, bool INV>
 __global__ __launch_bounds__(kBlock) void verify_kernel(const u64x2* __restrict__ buf, uint64_t n2, uint64_t span,
                                                         uint64_t base_word, uint64_t seed, VerifyOut* out) {
   uint64_t i = (uint64_t)blockIdx.x * span + threadIdx.x;
@@ -100,25 +122,41 @@ __global__ __launch_bounds__(kBlock) void verify_kernel(const u64x2* __restrict_
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
       const uint64_t w = base_word + 2 * (i + u * kBlock);
-      diff |= (v[u].x ^ expected_word(PAT, w, seed)) | (v[u].y ^ expected_word(PAT, w + 1, seed));
+      diff |= (v[u].x ^ want_word<PAT, INV>(w, seed)) | (v[u].y ^ want_word<PAT, INV>(w + 1, seed));
     }
     if (diff) {
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) {
         const uint64_t w = base_word + 2 * (i + u * kBlock);
-        const uint64_t e0 = expected_word(PAT, w, seed), e1 = expected_word(PAT, w + 1, seed);
-        if (v[u].x != e0) report(out, w, e0, v[u].x, PAT);
-        if (v[u].y != e1) report(out, w + 1, e1, v[u].y, PAT);
+        const uint64_t e0 = want_word<PAT, INV>(w, seed), e1 = want_word<PAT, INV>(w + 1, seed);
+        if (v[u].x != e0) report(out, w, e0, v[u].x, PAT, (const uint64_t*)(buf + i + u * kBlock));
+        if (v[u].y != e1) report(out, w + 1, e1, v[u].y, PAT, (const uint64_t*)(buf + i + u * kBlock) + 1);
       }
     }
   }
   for (; i < end; i += kBlock) {
     u64x2 v = __builtin_nontemporal_load(buf + i);
     const uint64_t w = base_word + 2 * i;
-    const uint64_t e0 = expected_word(PAT, w, seed), e1 = expected_word(PAT, w + 1, seed);
-    if (v.x != e0) report(out, w, e0, v.x, PAT);
-    if (v.y != e1) report(out, w + 1, e1, v.y, PAT);
+    const uint64_t e0 = want_word<PAT, INV>(w, seed), e1 = want_word<PAT, INV>(w + 1, seed);
+    if (v.x != e0) report(out, w, e0, v.x, PAT, (const uint64_t*)(buf + i));
+    if (v.y != e1) report(out, w + 1, e1, v.y, PAT, (const uint64_t*)(buf + i) + 1);
   }
+}
+
+// March element: read a word, check it against what the previous element left, write its complement.  One access
+// pair per lane over an in-order grid like the write pass; DOWN walks the region from its end (the classic march
+// goes through the addresses in both directions).  16 bytes read and 16 bytes written per lane.
+template <uint32_t PAT, bool INV, bool DOWN>
+__global__ __launch_bounds__(kBlock) void march_kernel(u64x2* __restrict__ buf, uint64_t n2, uint64_t base_word, uint64_t seed, VerifyOut* out) {
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n2) return;
+  if (DOWN) i = n2 - 1 - i;
+  const u64x2 v = __builtin_nontemporal_load(buf + i);
+  const uint64_t w = base_word + 2 * i;
+  const uint64_t e0 = want_word<PAT, INV>(w, seed), e1 = want_word<PAT, INV>(w + 1, seed);
+  if (v.x != e0) report(out, w, e0, v.x, PAT, (const uint64_t*)(buf + i));
+  if (v.y != e1) report(out, w + 1, e1, v.y, PAT, (const uint64_t*)(buf + i) + 1);
+  buf[i] = u64x2{~e0, ~e1};
 }
 
 // Host-side dispatch from the run-time pattern bit to the compile-time instance.
@@ -153,9 +191,32 @@ void launch_verify(const u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t p
   unsigned grid;
   uint64_t span;
   gmd::span_plan(n2, (uint64_t)kBlock * kUnroll, kVerifyMaxGrid, &grid, &span);
-#define CALL(P) verify_kernel<P><<<grid, kBlock, 0, st>>>(buf, n2, span, base_word, seed, out)
+#define CALL(P) verify_kernel<P, false><<<grid, kBlock, 0, st>>>(buf, n2, span, base_word, seed, out)
   GMD_FOR_PATTERN(pattern, CALL)
 #undef CALL
+}
+
+// One march element over a chunk: the region holds the pattern (inv = false) or its complement, and is left
+// holding the other.
+void launch_march(u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t pattern, uint64_t seed, bool inv, bool down, VerifyOut* out,
+                  hipStream_t st) {
+  constexpr uint64_t kPerLaunch = 1ull << 31;
+  // whole launches in address order going up, in reverse order going down
+  const uint64_t launches = (n2 + kPerLaunch - 1) / kPerLaunch;
+  for (uint64_t k = 0; k < launches; k++) {
+    const uint64_t off = (down ? launches - 1 - k : k) * kPerLaunch;
+    const uint64_t n = std::min(kPerLaunch, n2 - off);
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+#define CALL(P)                                                                                                          \
+  do {                                                                                                                   \
+    if (!inv && !down) march_kernel<P, false, false><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed, out); \
+    else if (inv && down) march_kernel<P, true, true><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed, out); \
+    else if (inv) march_kernel<P, true, false><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed, out);       \
+    else march_kernel<P, false, true><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed, out);                \
+  } while (0)
+    GMD_FOR_PATTERN(pattern, CALL)
+#undef CALL
+  }
 }
 
 __global__ void xor_word_kernel(unsigned long long* p, unsigned long long mask) { *p ^= mask; }
@@ -258,6 +319,17 @@ int gmd_memtest(int device, const gmd_memtest_config_t* cfg_in, gmd_memtest_resu
     gmd::set_error("memtest: out of memory for the result block");
     return GMD_ERR_NOMEM;
   }
+  // Twice the Infinity Cache of scrub space; without it (memory all taken) the test still runs, and says so.
+  constexpr uint64_t kScrubBytes = 512ull << 20;
+  void* scrub = nullptr;
+  if (hipMalloc(&scrub, kScrubBytes) != hipSuccess) {
+    (void)hipGetLastError();
+    scrub = nullptr;
+  }
+  out->scrubbed = scrub ? 1 : 0;
+  auto push_out = [&](uint64_t seed) {  // what the last pass left in the cache goes out to the memory cells
+    if (scrub) launch_fill((u64x2*)scrub, kScrubBytes / 16, 0, GMD_PAT_RANDOM, seed, 0);
+  };
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
@@ -266,7 +338,7 @@ int gmd_memtest(int device, const gmd_memtest_config_t* cfg_in, gmd_memtest_resu
   int npat = 0;
   for (uint32_t b = 0; b < 7; b++)
     if (cfg.patterns & (1u << b)) npat++;
-  const int total_steps = npat * (int)cfg.passes * 2;
+  const int total_steps = npat * (int)cfg.passes * 2 + (cfg.march ? 4 * (int)cfg.passes : 0);
   int step = 0;
   hipError_t err = hipSuccess;
   for (uint32_t pass = 0; pass < cfg.passes && err == hipSuccess; pass++) {
@@ -295,6 +367,7 @@ int gmd_memtest(int device, const gmd_memtest_config_t* cfg_in, gmd_memtest_resu
             xor_word_kernel<<<1, 1>>>((unsigned long long*)c.p + (word - c.base_word), cfg.inject_xor);
       }
       // ---- verify pass
+      push_out(seed);
       err = hipMemset(d_out, 0, sizeof(VerifyOut));
       if (err != hipSuccess) break;
       (void)hipEventRecord(e0, 0);
@@ -321,6 +394,58 @@ int gmd_memtest(int device, const gmd_memtest_config_t* cfg_in, gmd_memtest_resu
       out->patterns_run++;
       if (cfg.progress) cfg.progress((double)++step / total_steps, "verify", cfg.progress_user);
     }
+    // ---- march: write the random pattern, then up (check, write complement), down (check complement, write the
+    //      pattern), and a last check.  Every cell has been read after holding a value and its complement.
+    if (cfg.march && err == hipSuccess) {
+      const uint32_t pat = GMD_PAT_RANDOM;
+      const uint64_t seed = cfg.seed + pass * 7919 + 101;
+      for (auto& c : chunks) launch_fill((u64x2*)c.p, c.bytes / 16, c.base_word, pat, seed, 0);
+      if (cfg.inject_xor && cfg.inject_offset / 8 < got / 8) {
+        const uint64_t word = cfg.inject_offset / 8;
+        for (auto& c : chunks)
+          if (word >= c.base_word && word < c.base_word + c.bytes / 8)
+            xor_word_kernel<<<1, 1>>>((unsigned long long*)c.p + (word - c.base_word), cfg.inject_xor);
+      }
+      if (cfg.progress) cfg.progress((double)++step / total_steps, "march: write", cfg.progress_user);
+      err = hipMemset(d_out, 0, sizeof(VerifyOut));
+      double march_bytes = 0, march_s = 0;
+      for (int element = 0; element < 2 && err == hipSuccess; element++) {
+        const bool down = element == 1;
+        push_out(seed + element);
+        float ms = 0;
+        (void)hipEventRecord(e0, 0);
+        for (size_t k = 0; k < chunks.size(); k++) {
+          auto& c = chunks[down ? chunks.size() - 1 - k : k];
+          launch_march((u64x2*)c.p, c.bytes / 16, c.base_word, pat, seed, /*inv=*/down, down, d_out, 0);
+        }
+        (void)hipEventRecord(e1, 0);
+        err = hipEventSynchronize(e1);
+        if (err != hipSuccess) break;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        march_bytes += 2.0 * (double)got;
+        march_s += ms * 1e-3;
+        if (cfg.progress) cfg.progress((double)++step / total_steps, down ? "march: down" : "march: up", cfg.progress_user);
+      }
+      if (err == hipSuccess) {
+        push_out(seed + 2);
+        for (auto& c : chunks) launch_verify((const u64x2*)c.p, c.bytes / 16, c.base_word, pat, seed, d_out, 0);
+        VerifyOut h;
+        err = hipMemcpy(&h, d_out, sizeof h, hipMemcpyDeviceToHost);
+        if (err == hipSuccess) {
+          out->errors += h.errors;
+          for (uint32_t i = 0; i < h.logged && i < GMD_MEMTEST_LOG && out->logged < GMD_MEMTEST_LOG; i++) {
+            gmd_memtest_error_t e = h.log[i];
+            for (size_t ci = 0; ci < chunks.size(); ci++)
+              if (e.byte_offset / 8 >= chunks[ci].base_word && e.byte_offset / 8 < chunks[ci].base_word + chunks[ci].bytes / 8)
+                e.chunk = (uint32_t)ci;
+            out->log[out->logged++] = e;
+          }
+          out->march_passes++;
+          if (march_s > 0) out->march_tbps = march_bytes / march_s / 1e12;
+        }
+        if (cfg.progress) cfg.progress((double)++step / total_steps, "march: check", cfg.progress_user);
+      }
+    }
   }
   if (err == hipSuccess) err = hipGetLastError();
   out->seconds = now_s() - t_start;
@@ -331,6 +456,7 @@ int gmd_memtest(int device, const gmd_memtest_config_t* cfg_in, gmd_memtest_resu
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(d_out);
+  if (scrub) (void)hipFree(scrub);
   cleanup();
   if (err != hipSuccess) {
     gmd::set_error("memtest failed: %s", hipGetErrorString(err));

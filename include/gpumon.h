@@ -583,6 +583,9 @@ typedef struct {
   char message[192];
 } gm_diag_result_t;
 #define GM_DIAG_RESULT_VERSION GM_VERSION(gm_diag_result_t, 1)
+/* Results are kept per (GPU, test name).  A name is made of [A-Za-z0-9_.-]; once a GPU has this many, a result under
+ * a new name is refused with GM_ST_INSUFFICIENT_SIZE (results under known names keep replacing their predecessors). */
+#define GM_MAX_DIAG_TESTS 32
 GM_API gm_status_t gm_diag_result_submit(const gm_diag_result_t* r);
 /* Latest result per (GPU, test); *n in = capacity, out = count. */
 GM_API gm_status_t gm_diag_results(uint32_t gpu, gm_diag_result_t* out, int* n);

@@ -36,14 +36,16 @@ class StreamResult(C.Structure):
 
 class MemtestError(C.Structure):
     _fields_ = [("byte_offset", C.c_uint64), ("expected", C.c_uint64), ("actual", C.c_uint64),
-                ("pattern", C.c_uint32), ("chunk", C.c_uint32)]
+                ("pattern", C.c_uint32), ("chunk", C.c_uint32), ("device_address", C.c_uint64),
+                ("flipped_bits", C.c_uint32), ("page_offset", C.c_uint32)]
 
 
 class MemtestResult(C.Structure):
     _fields_ = [("bytes_tested", C.c_uint64), ("bytes_requested", C.c_uint64), ("errors", C.c_uint64),
                 ("patterns_run", C.c_uint32), ("chunks", C.c_uint32), ("write_tbps", C.c_double),
                 ("verify_tbps", C.c_double), ("seconds", C.c_double), ("logged", C.c_uint32),
-                ("log", MemtestError * MEMTEST_LOG)]
+                ("log", MemtestError * MEMTEST_LOG), ("scrubbed", C.c_uint32), ("march_passes", C.c_uint32),
+                ("march_tbps", C.c_double)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_double, C.c_char_p, C.c_void_p)
@@ -53,7 +55,7 @@ class MemtestConfig(C.Structure):
     _fields_ = [("bytes", C.c_uint64), ("fraction", C.c_double), ("chunk_bytes", C.c_uint64),
                 ("patterns", C.c_uint32), ("passes", C.c_uint32), ("seed", C.c_uint64),
                 ("inject_offset", C.c_uint64), ("inject_xor", C.c_uint64), ("progress", PROGRESS_CB),
-                ("progress_user", C.c_void_p)]
+                ("progress_user", C.c_void_p), ("march", C.c_uint32)]
 
 
 class MfmaResult(C.Structure):
@@ -137,8 +139,9 @@ def hbm_stream_launch(kernel, a, b, c, scalar, n_floats, nontemporal=False, stre
 
 
 def memtest(bytes=0, fraction=0.90, chunk_bytes=2 << 30, patterns=PAT_ALL, passes=1, seed=0, inject_offset=0,
-            inject_xor=0, progress=None, device=0):
+            inject_xor=0, progress=None, device=0, march=False):
     cfg = MemtestConfig()
+    cfg.march = int(march)
     cfg.bytes, cfg.fraction, cfg.chunk_bytes = bytes, fraction, chunk_bytes
     cfg.patterns, cfg.passes, cfg.seed = patterns, passes, seed
     cfg.inject_offset, cfg.inject_xor = inject_offset, inject_xor

@@ -285,3 +285,46 @@ def test_exporter_says_when_the_health_check_cannot_run(tmp_path):
             if p and p.poll() is None:
                 p.kill()
                 p.wait()
+
+
+def test_term_only_signals_a_host_engine(tmp_path):
+    """`gpumon-hostengine --term` reads a pid from a file that may be older than the process it named: a pid that now
+    belongs to something else is left alone, and said to be stale."""
+    pidfile = tmp_path / "he.pid"
+    victim = subprocess.Popen(["sleep", "30"])
+    try:
+        pidfile.write_text(f"{victim.pid}\n")
+        r = subprocess.run([bin_path("gpumon-hostengine"), "--term", "--pid-file", str(pidfile)], capture_output=True, text=True, timeout=30)
+        assert r.returncode == 1 and "is not a host engine" in r.stderr and "sleep" in r.stderr, r.stderr
+        assert victim.poll() is None                      # still running
+    finally:
+        victim.kill()
+        victim.wait()
+    r = subprocess.run([bin_path("gpumon-hostengine"), "--term", "--pid-file", str(pidfile)], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 1 and "is gone" in r.stderr, r.stderr
+
+
+def test_http_listens_on_ipv6_addresses(tmp_path):
+    import socket
+    import urllib.request
+    try:
+        s = socket.socket(socket.AF_INET6, socket.SOCK_STREAM)
+        s.bind(("::1", 0))
+        s.close()
+    except OSError:
+        pytest.skip("no IPv6 loopback on this host")
+    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=1")
+    ex = subprocess.Popen([bin_path("gpumon-exporter"), "-e", "-o", "", "--listen", "[::1]:0"], stderr=subprocess.PIPE, text=True, env=env)
+    try:
+        port = None
+        for _ in range(50):
+            m = re.search(r"Serving /metrics on port (\d+)", ex.stderr.readline())
+            if m:
+                port = int(m.group(1))
+                break
+        assert port
+        body = urllib.request.urlopen(f"http://[::1]:{port}/metrics", timeout=5).read().decode()
+        assert "dcgm_gpu_temp" in body
+    finally:
+        ex.terminate()
+        ex.wait(timeout=10)

@@ -16,6 +16,7 @@ import urllib.request
 import pytest
 
 from conftest import ROOT, bin_path
+from k8s_gpu_monitor_amd import abi as A
 from k8s_gpu_monitor_amd import engine as E
 from k8s_gpu_monitor_amd.utils.promparse import ExpositionError, parse
 
@@ -419,6 +420,80 @@ def test_diag_report_becomes_metrics(engine2, tmp_path):
         fams = parse(ex.render())
         assert fams["gpumon_diag_pass"].samples[0][1] == 0.0
         assert fams["gpumon_diag_memtest_errors"].samples[0][1] == 3.0
+
+
+def _verdict(test, health, gpu=None, bdf=None, system=4, message="m"):
+    v = {"test": test, "system": system, "health": health, "value": 1.0, "message": message}
+    if gpu is not None:
+        v["gpu"] = gpu
+    if bdf is not None:
+        v["pci_bdf"] = bdf
+    return v
+
+
+def test_node_wide_reports_never_speak_for_a_gpu(engine2, tmp_path):
+    """A directory as the scheduled diagnostics leave it: one report per GPU and two node-wide ones (link test, RCCL
+    sweep).  The node-wide reports pass; GPU 0's own report failed.  Files are merged in name order, and the node-wide
+    ones come last: gpumon_diag_pass{gpu="0"} must still say 0, the node-wide results get series of their own, and each
+    GPU's verdicts are there per test."""
+    d = tmp_path / "reports"
+    d.mkdir()
+    bdf = [E.device_attributes(i)["pci_bdf"] for i in range(2)]
+    gpu0 = dict(_diag_report(gpu=0, result="fail", errors=5), scope="gpu", pci_bdf=bdf[0],
+                verdicts=[_verdict("memtest", 20, message="memtest found 5 bad words"), _verdict("hbm_stream", 0)])
+    gpu1 = dict(_diag_report(gpu=1), scope="gpu", pci_bdf=bdf[1], verdicts=[_verdict("memtest", 0), _verdict("hbm_stream", 10)])
+    for doc in (gpu0, gpu1):
+        doc.pop("rccl"), doc.pop("p2p_gbps")
+    links = {"scope": "node", "timestamp": 1700000200, "result": "pass", "p2p_gbps": [[0, 58.5], [57.25, 0]],
+             "links": {"gpus": 2, "findings": [{"kind": "slow_link", "gpu": 1, "pci_bdf": bdf[1], "link": 3, "peer": 0, "health": 10}]},
+             "verdicts": [_verdict("xgmi_p2p", 0, gpu=0, bdf=bdf[0], system=2), _verdict("xgmi_p2p", 10, gpu=1, bdf=bdf[1], system=2)]}
+    rccl = {"scope": "node", "timestamp": 1700000300, "result": "pass",
+            "rccl": {"gpus": 2, "points": [], "peak_busbw_gbps": {"all_reduce": 61.5}, "expected_busbw_gbps": {"all_reduce": 53.76}},
+            "verdicts": [_verdict("rccl", 0, system=2)]}
+    for name, doc in (("gpu0.json", gpu0), ("gpu1.json", gpu1), ("links.json", links), ("rccl.json", rccl)):
+        _write_json(d / name, doc)
+    with E.Exporter(diag_results_path=str(d)) as ex:
+        ex.sweep()
+        fams = parse(ex.render())
+        assert {l["gpu"]: v for l, v in fams["gpumon_diag_pass"].samples} == {"0": 0.0, "1": 1.0}
+        assert {l["gpu"]: v for l, v in fams["gpumon_diag_timestamp_seconds"].samples} == {"0": 1700000123.0, "1": 1700000123.0}
+        assert {l["report"]: v for l, v in fams["gpumon_diag_node_pass"].samples} == {"links": 1.0, "rccl": 1.0}
+        assert {l["report"]: v for l, v in fams["gpumon_diag_node_timestamp_seconds"].samples} == {"links": 1700000200.0, "rccl": 1700000300.0}
+        th = {(l["gpu"], l["test"]): v for l, v in fams["gpumon_diag_test_health"].samples}
+        assert th == {("0", "memtest"): 20, ("0", "hbm_stream"): 0, ("1", "memtest"): 0, ("1", "hbm_stream"): 10,
+                      ("0", "xgmi_p2p"): 0, ("1", "xgmi_p2p"): 10}, th       # the node-wide rccl verdict names no GPU
+        assert fams["gpumon_diag_link_findings"].samples == [({"gpu": "1", "kind": "slow_link"}, 1.0)]
+        assert fams["gpumon_diag_rccl_expected_busbw_gbps"].samples == [({"gpus": "2", "op": "all_reduce"}, 53.76)]
+        # and the engine was told, GPU by GPU
+        r0 = {x["test"]: x["health"] for x in E.diag_results(0)}
+        r1 = {x["test"]: x["health"] for x in E.diag_results(1)}
+        assert r0 == {"memtest": 20, "hbm_stream": 0, "xgmi_p2p": 0} and r1 == {"memtest": 0, "hbm_stream": 10, "xgmi_p2p": 10}
+
+
+def test_reports_find_their_gpu_by_pci_address(engine2, tmp_path):
+    """The diagnostics number GPUs the way the compute runtime does, the engine follows the PCI bus, and a diagnostics
+    container may see a subset of the cards.  A report that calls a card "gpu 0" but carries the PCI address of the
+    engine's GPU 1 is GPU 1's, series and health incident alike; a report about a card the engine does not have is left
+    out rather than blamed on whichever GPU has that number."""
+    d = tmp_path / "reports"
+    d.mkdir()
+    bdf1 = E.device_attributes(1)["pci_bdf"]
+    doc = dict(_diag_report(gpu=0, result="fail", errors=2), scope="gpu", pci_bdf=bdf1.upper(),
+               verdicts=[_verdict("memtest", 20, message="memtest found 2 bad words")])
+    _write_json(d / "a.json", doc)
+    stranger = dict(_diag_report(gpu=0, result="fail"), scope="gpu", pci_bdf="0000:ff:1f.0", verdicts=[_verdict("memtest", 20)])
+    _write_json(d / "b.json", stranger)
+    with E.Exporter(diag_results_path=str(d)) as ex:
+        ex.sweep()
+        fams = parse(ex.render())
+        assert fams["gpumon_diag_pass"].samples == [({"gpu": "1"}, 0.0)]
+        assert fams["gpumon_diag_memtest_errors"].samples == [({"gpu": "1"}, 2.0)]
+        assert fams["gpumon_diag_test_health"].samples == [({"gpu": "1", "test": "memtest"}, 20.0)]
+        assert E.diag_results(0) == [] and [x["test"] for x in E.diag_results(1)] == ["memtest"]
+        g = E.group_create("bdf", [0, 1])
+        E.health_set(g, A.HEALTH["ALL"])
+        status = {h["gpu"]: h["status"] for h in E.health_check(g)}
+        assert status == {0: "Healthy", 1: "Failure"}
 
 
 def test_diag_report_directory_and_garbage(engine2, tmp_path):

@@ -153,6 +153,28 @@ def test_memtest_driver_with_injection(diag):
     assert big["errors"] == 0 and big["write_tbps"] > 5.3 and big["verify_tbps"] > 5.3, big
 
 
+def test_memtest_march_scrub_and_locatable_errors(diag):
+    """The march (read, check, write the complement; up, then down) finds a flipped bit like the pattern passes do, a
+    clean region passes it, and it moves memory at stream rate in both directions at once.  Every pass is checked only
+    after a scrub of twice the Infinity Cache, and an error record says where the word is: region offset, chunk,
+    device address, offset in its 4 KiB page and how many bits differ."""
+    off = (300 << 20) + 4096 * 3 + 64
+    r = diag.memtest(bytes=1 << 30, chunk_bytes=256 << 20, patterns=diag.PATTERNS["address"], march=True,
+                     inject_offset=off, inject_xor=0x5000)
+    assert r["scrubbed"] == 1 and r["march_passes"] == 1 and r["patterns_run"] == 1
+    assert r["errors"] == 2 and len(r["log"]) == 2      # once in the pattern pass, once going up in the march
+    for e in r["log"]:
+        assert e["byte_offset"] == off and e["chunk"] == 1 and e["flipped_bits"] == 2 and e["expected"] ^ e["actual"] == 0x5000
+        assert e["device_address"] % 8 == 0 and e["page_offset"] == e["device_address"] % 4096 == 64
+    # the two chunk-1 records are the same word of the same allocation
+    assert r["log"][0]["device_address"] == r["log"][1]["device_address"]
+    clean = diag.memtest(bytes=8 << 30, patterns=diag.PATTERNS["random"], march=True)
+    assert clean["errors"] == 0 and clean["march_passes"] == 1 and clean["scrubbed"] == 1
+    assert clean["march_tbps"] > 4.5, clean   # bytes read + written per second
+    # the scrub costs next to nothing at this size
+    assert clean["write_tbps"] > 5.3 and clean["verify_tbps"] > 5.0, clean
+
+
 # ------------------------------------------------------------------- MFMA GEMM --
 class _Gemm:
     """Operands of one GEMM case: A [m,k], B [n,k]; for MX-fp8 also row-major E8M0 scales [rows, k/32] and their

@@ -249,6 +249,25 @@ def test_link_test_report_carries_one_verdict_per_gpu(engine, tmp_path):
     assert res[1]["status"] == "Failure" and res[0]["status"] == "Healthy"
 
 
+def test_diagnostic_results_are_bounded_and_their_names_plain(engine):
+    """Any client of the engine may hand in verdicts.  A test name ends up in label values, JSON and fixed-size reply
+    arrays: it must be a plain identifier, and a GPU keeps at most 32 of them; a known name keeps being replaced."""
+    from k8s_gpu_monitor_amd._lib import GpumonError
+    for bad in ('mem"test', "a b", "x/y", "tab\tname", "\u00e9"):
+        with pytest.raises(GpumonError) as e:
+            E.diag_result_submit(0, bad, H["MEM"], A.HEALTH_PASS)
+        assert e.value.status == A.GM_ST_BADPARAM, bad
+    for i in range(32):
+        E.diag_result_submit(0, f"test-{i}.v1_x", H["MEM"], A.HEALTH_PASS)
+    with pytest.raises(GpumonError) as e:
+        E.diag_result_submit(0, "one-too-many", H["MEM"], A.HEALTH_FAIL)
+    assert e.value.status == A.GM_ST_INSUFFICIENT_SIZE
+    E.diag_result_submit(0, "test-7.v1_x", H["MEM"], A.HEALTH_WARN, "still replaceable")
+    res = {d["test"]: d["health"] for d in E.diag_results(0)}
+    assert len(res) == 32 and res["test-7.v1_x"] == A.HEALTH_WARN
+    E.diag_result_submit(1, "one-too-many", H["MEM"], A.HEALTH_PASS)   # the bound is per GPU
+
+
 def test_links_and_diagnostics_views_cli_and_rest(engine, tmp_path):
     """`gpumon links`, `gpumon diag`, and the REST routes /gpumon/links/id/N and /gpumon/diag/id/N (text and /json)."""
     import signal
