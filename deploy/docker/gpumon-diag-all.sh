@@ -1,11 +1,14 @@
 #!/bin/bash
-# Runs the diagnostics on every GPU the container (or the host) sees, one GPU after the other, and leaves one report
-# per GPU in $GPUMON_DIAG_DIR for `gpumon-exporter --diag-results DIR`.  With more than one GPU it ends with the
-# xGMI link test and a short RCCL sweep over all of them.  Exit status: 0 when every test passed, 1 when a test
-# failed, 2 when the diagnostics could not run or a step died (nothing is started after a step that was killed).
-#   GPUMON_DIAG_LEVEL   1 (seconds), 2 (about a minute per GPU, default), 3 (soak)
-#   GPUMON_DIAG_DIR     report directory (default /var/lib/gpumon/diag)
-#   GPUMON_DIAG_SUBMIT  address of a host engine that also gets the verdicts (e.g. 127.0.0.1:5555); empty = none
+# Runs the diagnostics on every GPU the container (or the host) sees and leaves the reports in $GPUMON_DIAG_DIR for
+# `gpumon-exporter --diag-results DIR`.  All GPUs are loaded at the same time, step by step (one process, one host
+# thread per GPU): that is what the node's power delivery and cooling have to carry in production, and every GPU is
+# also held against the median of the others.  The fabric tests (xGMI link test, RCCL sweep) run once over all GPUs,
+# not once per GPU.  Exit status: 0 when every test passed (warnings included), 1 when a test failed, 2 when the
+# diagnostics could not run or a step died (nothing is started after a step that was killed).
+#   GPUMON_DIAG_LEVEL       1 (seconds), 2 (about a minute, default), 3 (whole-HBM sweep, 60 s soak, fabric)
+#   GPUMON_DIAG_DIR         report directory (default /var/lib/gpumon/diag)
+#   GPUMON_DIAG_SUBMIT      address of a host engine that also gets the verdicts (e.g. 127.0.0.1:5555); empty = none
+#   GPUMON_DIAG_SEQUENTIAL  1 = one GPU after the other (one report per GPU, no comparison between GPUs)
 set -u
 LEVEL=${GPUMON_DIAG_LEVEL:-2}
 DIR=${GPUMON_DIAG_DIR:-/var/lib/gpumon/diag}
@@ -28,17 +31,29 @@ note() {  # keep the worst status: 2 (could not run) over 1 (failed) over 0
   [ "$1" -gt "$worst" ] && worst=$1
   return 0
 }
-for ((g = 0; g < n; g++)); do
-  echo "=== GPU $g: level $LEVEL"
-  "$DIAG" run -r "$LEVEL" -g "$g" --publish "$DIR/gpu$g.json" "${extra[@]}"
+if [ "${GPUMON_DIAG_SEQUENTIAL:-0}" = 1 ]; then
+  rm -f "$DIR/node.json"  # the report of an earlier concurrent run would contradict the ones written now
+  for ((g = 0; g < n; g++)); do
+    echo "=== GPU $g: level $LEVEL"
+    "$DIAG" run -r "$LEVEL" -g "$g" --no-fabric --publish "$DIR/gpu$g.json" "${extra[@]}"
+    note $?
+  done
+else
+  rm -f "$DIR"/gpu[0-9].json "$DIR"/gpu[0-9][0-9].json  # per-GPU reports of an earlier sequential run
+  echo "=== $n GPU(s) at once: level $LEVEL"
+  "$DIAG" run -r "$LEVEL" --gpus all --no-fabric --publish "$DIR/node.json" "${extra[@]}"
   note $?
-done
+fi
 if [ "$n" -gt 1 ]; then
   echo "=== xGMI links"
   "$DIAG" links --publish "$DIR/links.json" "${extra[@]}"
   note $?
   echo "=== RCCL"
-  "$DIAG" rccl --max-bytes 256M --factor 16 --publish "$DIR/rccl.json" "${extra[@]}"
+  if [ "$LEVEL" -ge 3 ]; then
+    "$DIAG" rccl --scaling --publish "$DIR/rccl.json" "${extra[@]}"
+  else
+    "$DIAG" rccl --max-bytes 256M --factor 16 --publish "$DIR/rccl.json" "${extra[@]}"
+  fi
   note $?
 fi
 exit "$worst"

@@ -180,8 +180,9 @@ def test_one_listener_per_port_in_every_pod(tmp_path):
 
 
 def test_all_gpu_diagnostics_wrapper(tmp_path):
-    """deploy/docker/gpumon-diag-all.sh with a stand-in for gpumon-diag: one run per GPU, link test and RCCL sweep only
-    with more than one GPU, reports in the directory, the worst exit status wins, flags are ones gpumon-diag knows."""
+    """deploy/docker/gpumon-diag-all.sh with a stand-in for gpumon-diag: one run that loads all GPUs at once (or one run
+    per GPU when asked for), the fabric tests once and only with more than one GPU, reports in the directory, the worst
+    exit status wins, nothing is started after a step that died, flags are ones gpumon-diag knows."""
     script = os.path.join(DEPLOY, "docker", "gpumon-diag-all.sh")
     stub = tmp_path / "gpumon-diag"
     stub.write_text("""#!/bin/bash
@@ -194,6 +195,8 @@ prev=""
 for a in "$@"; do [ "$prev" = --publish ] && echo '{}' > "$a"; prev=$a; done
 [ "$1" = run ] && [ "$4" = "-g" ] && [ "$5" = "${STUB_FAIL_GPU:-none}" ] && exit 1
 [ "$1" = run ] && [ "$4" = "-g" ] && [ "$5" = "${STUB_CRASH_GPU:-none}" ] && kill -SEGV $$
+[ "$1" = run ] && [ "$4" = "--gpus" ] && [ -n "${STUB_FAIL_NODE:-}" ] && exit 1
+[ "$1" = run ] && [ "$4" = "--gpus" ] && [ -n "${STUB_CRASH_NODE:-}" ] && kill -SEGV $$
 exit 0
 """)
     stub.chmod(0o755)
@@ -206,17 +209,28 @@ exit 0
         return r.returncode, calls, sorted(p.name for p in out.iterdir()) if out.exists() else []
 
     rc, calls, files = run(1)
-    assert rc == 0 and calls == ["info", f"run -r 2 -g 0 --publish {tmp_path}/out10/gpu0.json"] and files == ["gpu0.json"]
-    rc, calls, files = run(3, GPUMON_DIAG_LEVEL="1", GPUMON_DIAG_SUBMIT="127.0.0.1:5555", STUB_FAIL_GPU="1")
+    assert rc == 0 and calls == ["info", f"run -r 2 --gpus all --no-fabric --publish {tmp_path}/out10/node.json"] and files == ["node.json"]
+    # all GPUs at once; the fabric tests once
+    rc, calls, files = run(8, GPUMON_DIAG_LEVEL="3", GPUMON_DIAG_SUBMIT="127.0.0.1:5555", STUB_FAIL_NODE="1")
+    assert rc == 1 and len(calls) == 4 and files == ["links.json", "node.json", "rccl.json"]
+    assert calls[1].startswith("run -r 3 --gpus all --no-fabric --publish") and calls[1].endswith("--submit 127.0.0.1:5555")
+    assert calls[2].startswith("links --publish") and calls[3].startswith("rccl --scaling --publish")
+    rc, calls, files = run(2, X="1")
+    assert rc == 0 and calls[3].startswith("rccl --max-bytes 256M --factor 16 --publish")
+    # one GPU after the other, when asked for
+    rc, calls, files = run(3, GPUMON_DIAG_LEVEL="1", GPUMON_DIAG_SEQUENTIAL="1", STUB_FAIL_GPU="1")
     assert rc == 1 and len(calls) == 1 + 3 + 2 and files == ["gpu0.json", "gpu1.json", "gpu2.json", "links.json", "rccl.json"]
-    assert calls[2].startswith("run -r 1 -g 1 ") and calls[2].endswith("--submit 127.0.0.1:5555")
-    assert calls[4].startswith("links --publish") and calls[5].startswith("rccl --max-bytes 256M --factor 16 --publish")
+    assert calls[2].startswith("run -r 1 -g 1 --no-fabric ")
     assert run(0)[0] == 2
-    rc, calls, files = run(4, STUB_CRASH_GPU="1", X="1", Y="2")  # GPU 1's run dies: GPUs 2 and 3, links and RCCL are not started
+    rc, calls, files = run(4, GPUMON_DIAG_SEQUENTIAL="1", STUB_CRASH_GPU="1", X="1", Y="2")  # GPU 1's run dies: GPUs 2 and 3, links and RCCL are not started
     assert rc == 2 and [c.split()[0:5] for c in calls[1:]] == [["run", "-r", "2", "-g", "0"], ["run", "-r", "2", "-g", "1"]]
+    rc, calls, files = run(4, STUB_CRASH_NODE="1", X="1")      # the concurrent run dies: no fabric test is started
+    assert rc == 2 and len(calls) == 2
     # every flag the script passes is one the real binary parses
     src = open(os.path.join(ROOT, "cmd", "gpumon-diag.cc")).read()
-    for flag in ("-r", "-g", "--publish", "--submit", "--max-bytes", "--factor"):
+    for flag in ("-r", "-g", "--gpus", "--publish", "--submit", "--max-bytes", "--factor"):
+        assert f'"{flag}"' in src, flag
+    for flag in ("--no-fabric", "--scaling"):
         assert f'"{flag}"' in src, flag
     ep = _entrypoint("gpumon-diag.Dockerfile")
     assert ep == ["gpumon-diag-all"] and "gpumon-diag-all.sh /usr/local/bin/gpumon-diag-all" in open(

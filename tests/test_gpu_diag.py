@@ -572,7 +572,8 @@ def test_cli_report_is_published_and_exported(tmp_path):
     r = subprocess.run([bin_path("gpumon-diag"), "run", "-r", "1", "--publish", str(rep)],
                        capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout + r.stderr
-    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=1,steady=1")
+    # the exporter runs on the device library: a report finds its GPU by the PCI address it carries
+    env = dict(os.environ, GPUMON_BACKEND="amdsmi")
     r = subprocess.run([bin_path("gpumon-exporter"), "-e", "--once", "-o", str(out), "--diag-results", str(tmp_path)],
                        env=env, capture_output=True, text=True, timeout=30)
     assert r.returncode == 0, r.stderr
@@ -602,7 +603,8 @@ def test_soak_reports_matrix_pipe_activity_from_the_hardware_counter(tmp_path):
     m = report["mfma_active"]
     assert m["windows"] >= 4 and 40.0 < m["avg"] <= 100.0 and m["max"] >= m["avg"] >= m["min"], m
     assert 1000 < m["clock_mhz"] < 2600
-    env = dict(os.environ, GPUMON_BACKEND="fake", GPUMON_BACKEND_SPEC="gpus=1,steady=1")
+    # the exporter runs on the device library: a report finds its GPU by the PCI address it carries
+    env = dict(os.environ, GPUMON_BACKEND="amdsmi")
     r = subprocess.run([bin_path("gpumon-exporter"), "-e", "--once", "-o", str(out), "--diag-results", str(tmp_path)],
                        env=env, capture_output=True, text=True, timeout=30)
     assert r.returncode == 0, r.stderr
