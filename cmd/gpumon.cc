@@ -190,7 +190,7 @@ static int cmd_ps(const std::vector<std::string>& a) {
   printf("# gpu   pid   type  mem  Command\n# Idx     #   C/G   MiB  name\n");
   for (uint32_t g = 0; g < n; g++) {  // where the list comes from on this host (device library table, /proc statistics, open files)
     char src[32] = "";
-    if (gm_process_source(g, src, sizeof src) == GM_ST_OK) printf("# gpu %u: process list from %s\n", g, src);
+    if (gm_process_source(g, src, sizeof src) == GM_ST_OK) fprintf(stderr, "gpu %u: process list from %s\n", g, src);  // a note, not part of the table
   }
   for (int it = 0; !g_stop && (count == 0 || it < count); it++) {
     if (it) sleep_ms(1000);

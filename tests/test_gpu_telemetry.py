@@ -198,7 +198,7 @@ def test_own_process_is_attributed(hw):
         assert 1 << 30 <= mine[0]["vram_bytes"] < 1 << 40
     r = subprocess.run([bin_path("gpumon"), "ps", "-c", "1"], capture_output=True, text=True, timeout=60,
                        env=dict(os.environ, GPUMON_BACKEND="amdsmi"))
-    assert r.returncode == 0 and f"process list from {src}" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and f"process list from {src}" in r.stderr, r.stdout + r.stderr
     assert any(line.split()[1:2] == [str(os.getpid())] for line in r.stdout.splitlines() if not line.startswith("#")), r.stdout
     del keep
 
