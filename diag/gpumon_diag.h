@@ -194,8 +194,11 @@ GMD_API int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int r
  * 4 / 5 = schedule 1 with the narrow / the cached epilogue (A/B references); 6 = schedule 2 as one stream per
  * CU (A/B reference, same conditions as 3, otherwise 2 runs).  Partial tiles run the general four-wave kernel
  * whatever the schedule, an odd number of K-tiles does unless the schedule is 0.  MX-fp8 runs 2, 6 or 0.
- * 7 = schedule 2 on the K=32 instruction for unscaled fp8 (2 for the other data types).  All schedules give
- * bit-identical results, except that unscaled fp8 has two groups of them, one per MFMA instruction (K=128: -1, 2, 6;
+ * 7 = schedule 2 on the K=32 instruction for unscaled fp8 (2 for the other data types).
+ * 8 = 128 x 128 tiles, four waves of 64 x 64, two workgroups per CU (bf16 and fp8, any M, N in multiples of 8): what
+ * the default picks where the 256 x 256 tiles cannot fill the chip (2048^3 is 64 of them on 256 CUs); MX-fp8 runs 2.
+ * All schedules give
+ * bit-identical results, except that unscaled fp8 has two groups of them, one per MFMA instruction (K=128: -1, 2, 6, 8;
  * K=32: the others), whose sums differ in the order of their additions.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
 

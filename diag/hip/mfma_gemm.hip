@@ -221,7 +221,7 @@ __device__ uint4 g_gemm_zero_slab[264];  // 4 KiB + 128 B: the odd K-tile of a p
 template <int DT>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes,
-                                                           const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB) {
+                                                           const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB, int) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -458,7 +458,7 @@ __device__ unsigned long long g_gemm_timeline[4 * kStampSlots];
 template <int DT, int ABL = 0, int AHEAD = kAheadDefault, int EPI = 1>
 __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes,
-                                                           const uint32_t*, const uint32_t*) {  // no scales: bf16 / fp8 only
+                                                           const uint32_t*, const uint32_t*, int) {  // no scales: bf16 / fp8 only
   constexpr int kAhead = AHEAD;  // half-tiles issued ahead of the running phase; kAhead - 2 of them are in flight
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(kThreads) void gemm_pp_kernel(const char* __restric
 template <int DT, int EPI = 1, int ABL = 0>  // ABL 16: clock stamps and per-tile timeline (ablation builds only)
 __global__ __launch_bounds__(kThreads) void gemm_ps_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                            __bf16* __restrict__ C, int M, int N, size_t row_bytes,
-                                                           const uint32_t*, const uint32_t*) {  // no scales: bf16 / fp8 only
+                                                           const uint32_t*, const uint32_t*, int) {  // no scales: bf16 / fp8 only
   constexpr int kAhead = kAheadDefault;
   static_assert(kAhead == 7, "the mode tables below are written for an issue distance of seven half-tiles");
   constexpr int kStores = EPI ? 16 : 32;  // store instructions per wave of one tile (store_acc)
@@ -986,7 +986,9 @@ __device__ __forceinline__ void w4_wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07
 template <int DT, int ABL = 0, int EPI = 1, bool STREAM = false, bool GEN = false, bool UNIT = false>
 __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restrict__ A, const char* __restrict__ B,
                                                              __bf16* __restrict__ C, int M, int N, size_t row_bytes,
-                                                             const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB) {
+                                                             const uint32_t* __restrict__ SA, const uint32_t* __restrict__ SB, int ldc) {
+  // ldc: C's row stride in elements; N where the launch covers the whole matrix, larger where it covers the leading
+  // columns of a wider one (launch_gemm_t).  Only the epilogue reads it.
   constexpr bool kMx = DT == GMD_DT_MXFP8;    // the K=128 instruction and its layouts
   constexpr bool kScaled = kMx && !UNIT;      // ... with scale tensors
   static_assert(!UNIT || kMx, "UNIT is a form of the MX-fp8 kernel");
@@ -1449,8 +1451,8 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     for (int i = 0; i < 8; i++)
 #pragma unroll
       for (int j = 0; j < 8; j++) asm volatile("" : "+a"(acc[i][j]));
-    if constexpr (kRowsDealt) store_acc_rows<EPI, true>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq);
-    else store_acc<8, EPI, true>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
+    if constexpr (kRowsDealt) store_acc_rows<EPI, true>(acc, C, (size_t)ldc, tm * BM + wr * 128, tn * BN + wc * 128, fr, fq);
+    else store_acc<8, EPI, true>(acc, C, (size_t)ldc, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
     if (!has_next) break;
 #pragma unroll
     for (int i = 0; i < 8; i++)
@@ -1498,9 +1500,9 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     // that live through the K loop for nothing, and that the register allocator may decide to spill and reload here.
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
-    if constexpr (kRowsDealt && GEN) store_acc_rows_edge<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e, M, N);
-    else if constexpr (kRowsDealt) store_acc_rows<EPI>(acc, C, (size_t)N, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e);
-    else store_acc<8, EPI>(acc, C, (size_t)N, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
+    if constexpr (kRowsDealt && GEN) store_acc_rows_edge<EPI>(acc, C, (size_t)ldc, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e, M, N);
+    else if constexpr (kRowsDealt) store_acc_rows<EPI>(acc, C, (size_t)ldc, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e);
+    else store_acc<8, EPI>(acc, C, (size_t)ldc, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
   }
 #ifdef GMD_GEMM_ABLATE
   if constexpr (ABL & 16) {
@@ -1769,8 +1771,234 @@ double peak_flops_per_mfma(int dt) {
 // 6 = four waves of 128 x 128 as one stream per CU over its tiles (gemm_w4_kernel<.., STREAM>);
 // 7 = schedule 2 on the K=32 fp8 instruction (unscaled fp8 only, where 2 and 6 run the K=32 sums' products on the K=128
 // instruction, which adds them up in another order: an A/B reference; schedule 2 for the other data types).
+// ---- (2f) small tiles for small problems -----------------------------------------
+//
+// The 256 x 256 tile of the pipelines above is what a large GEMM wants (one wave holds 128 x 128 of C and reads each
+// operand byte from LDS once per 128 columns), but a problem with fewer such tiles than the chip has CUs leaves CUs
+// idle: 2048^3 is 64 tiles on 256 CUs.  This kernel computes 128 x 128 tiles with four waves of 64 x 64 over a ring of
+// K-tile stages in LDS (A and B, 32 KiB per stage): stage t + NSTAGE - 1 is issued before stage t is computed on, so
+// that the memory latency of several K-tiles (a K-tile is only 32 MFMAs per wave here) is in flight at any time;
+// one counted vmcnt wait and one barrier per K-tile.  Same LDS image and swizzle as gemm_kernel, same order of the sums (K-tiles in
+// order, k-substeps in order), so bf16 results are bit-identical to every other schedule's and fp8 results to the
+// K=128 schedules'.  A 64 x 64 wave tile reads 8 fragments per 16 MFMAs, which is all the LDS can deliver, so this is
+// no kernel for large problems; the dispatcher uses it where the large tiles cannot fill the chip.
+// Any M, any N that is a multiple of 8, whole K-tiles: rows beyond the matrix are fetched from its last row and
+// their results are not stored.
+constexpr int kS128 = 128;
+constexpr int kS128Threads = 256;
+constexpr int kS128TileBytes = kS128 * BKB;  // 16 KiB per operand per stage
+constexpr int kS128Stages = 5;               // 160 KiB: all of a CU's LDS, four K-tiles in flight
+constexpr int kS128LdsBytes = kS128Stages * 2 * kS128TileBytes;
+
+// One launch covers up to two regions of one GEMM (the right and the bottom strip of a matrix whose bulk runs on the
+// large tiles): workgroups [0, tiles0) are region 0's tiles, the rest region 1's.  Both share K and C's row stride.
+struct S128Region {
+  const char *a, *b;  // first row of the region's A rows / B rows (B is [N, K])
+  __bf16* c;          // the region's first element of C
+  int m, n;
+};
+struct S128Args {
+  S128Region r[2];
+  int tiles0;
+  int ldc;
+  size_t row_bytes;
+};
+
+template <int DT, int NSTAGE = kS128Stages>
+__global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args args) {
+  const int region = (int)blockIdx.x >= args.tiles0 ? 1 : 0;  // workgroup-uniform
+  const char* __restrict__ A = args.r[region].a;
+  const char* __restrict__ B = args.r[region].b;
+  __bf16* __restrict__ C = args.r[region].c;
+  const int M = args.r[region].m, N = args.r[region].n, ldc = args.ldc;
+  const size_t row_bytes = args.row_bytes;
+  static_assert(DT == GMD_DT_BF16 || DT == GMD_DT_FP8, "bf16 and unscaled fp8");
+  static_assert(NSTAGE >= 3 && NSTAGE <= 5, "stage t + 1 is read while stage t is computed on; the wait ladder knows up to three later stages");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // XCD-aware tile assignment (bijective for any grid size), tiles walked in groups that share operand panels in L2.
+  const int tiles_m = (M + kS128 - 1) / kS128, tiles_n = (N + kS128 - 1) / kS128;
+  const int nwg = region ? (int)gridDim.x - args.tiles0 : args.tiles0, bid = (int)blockIdx.x - (region ? args.tiles0 : 0);
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int tm, tn;
+  tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
+  const int rows_a = min(M - tm * kS128, kS128), rows_b = min(N - tn * kS128, kS128);
+  const char* gA = A + (size_t)tm * kS128 * row_bytes;
+  const char* gB = B + (size_t)tn * kS128 * row_bytes;
+
+  // Staging: 16 pieces of 8 rows per operand tile; wave w issues pieces 4w..4w+3 of A and of B.  Lane i of a piece
+  // lands at piece_base + 16 i and fetches row i >> 3, source chunk (i & 7) ^ f(i >> 3).
+  const int r8 = lane >> 3;
+  const int src_chunk = ((lane & 7) ^ chunk_swizzle<DT>(r8)) * 16;
+  size_t src_a[4], src_b[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = (wave * 4 + i) * 8 + r8;
+    src_a[i] = (size_t)min(row, rows_a - 1) * row_bytes + src_chunk;
+    src_b[i] = (size_t)min(row, rows_b - 1) * row_bytes + src_chunk;
+  }
+  // LDS-DMA instruction j (0..7) of a stage: piece j >> 1 of this wave's four, A (even j) or B (odd j).
+  auto stage_one = [&](int j, int kt, char* buf) {
+    const int i = j >> 1, piece = wave * 4 + i;
+    if (j & 1)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + src_b[i] + (size_t)kt * BKB),
+                                       (__attribute__((address_space(3))) void*)(buf + kS128TileBytes + piece * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + src_a[i] + (size_t)kt * BKB),
+                                       (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+  };
+  auto stage_both = [&](int kt, char* buf) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) stage_one(j, kt, buf);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Fragments: lane (fr, fq) reads row fr of a 16-row block, chunks fq and 4 + fq (bf16: the two k-substeps; fp8: the
+  // two halves of the K=128 operand).
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    a_off[h] = lds_off<DT>(wr * 64 + fr, 4 * h + fq);
+    b_off[h] = lds_off<DT>(wc * 64 + fr, 4 * h + fq);
+  }
+
+  const int nt = (int)(row_bytes / BKB);
+  // The fragments of a whole K-tile: eight 16-byte reads per operand (four 16-row blocks x two 64-byte halves).
+  struct Frags {
+    i32x4 a[4][2], b[4][2];
+  };
+  // Fragment read r (0..15) of a stage: B blocks first (r 0..7: block r >> 1, half r & 1), then A.
+  auto read_one = [&](Frags& f, int r, const char* la) {
+    const int blk = (r & 7) >> 1, h = r & 1;
+    if (r < 8) f.b[blk][h] = *(const i32x4*)(la + kS128TileBytes + b_off[h] + blk * 2048);
+    else f.a[blk][h] = *(const i32x4*)(la + a_off[h] + blk * 2048);
+  };
+  auto read_frags = [&](Frags& f, int ring_slot) {
+    const char* la = smem + ring_slot * 2 * kS128TileBytes;
+#pragma unroll
+    for (int r = 0; r < 16; r++) read_one(f, r, la);
+  };
+  auto mfmas = [&](const Frags& f) {
+    if constexpr (DT == GMD_DT_BF16) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+          for (int nb = 0; nb < 4; nb++)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[nb][ks]), __builtin_bit_cast(bf16x8, f.a[mb][ks]),
+                                                                  acc[mb][nb], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+        for (int nb = 0; nb < 4; nb++) {  // unscaled: both scales 2^0 (E8M0 127)
+          const i32x4 bl = f.b[nb][0], bh = f.b[nb][1], al = f.a[mb][0], ah = f.a[mb][1];
+          acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(i32x8{bl.x, bl.y, bl.z, bl.w, bh.x, bh.y, bh.z, bh.w},
+                                                                         i32x8{al.x, al.y, al.z, al.w, ah.x, ah.y, ah.z, ah.w}, acc[mb][nb], 0, 0, 0,
+                                                                         0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    }
+  };
+  // Stage j has landed once at most `later` of the stages issued after it are outstanding (eight LDS-DMA instructions
+  // per wave and stage).
+  auto wait_stage = [&](int later) {
+    if (later >= 3) wait_vmcnt<24>();
+    else if (later == 2) wait_vmcnt<16>();
+    else if (later == 1) wait_vmcnt<8>();
+    else wait_vmcnt<0>();
+  };
+  // One K-tile: make sure stage t + 1 has landed everywhere (and that every wave has left stage t - 1 behind, whose
+  // slot is filled next), then the eight LDS-DMA instructions of stage t + NSTAGE - 1 and the 16 fragment reads of
+  // stage t + 1 in the shadow of the MFMAs of stage t.  With one wave per SIMD nothing else hides an LDS read or the
+  // issue of an LDS-DMA instruction, so they are dealt out between the MFMAs: the source states the memory
+  // instructions in the order wanted (the compiler will not reorder an LDS-DMA write against an LDS read) and the
+  // scheduler is told where the MFMAs go.  STEADY: stage t + NSTAGE - 1 exists, no branch in the body.
+  auto ktile = [&](auto STEADY, int t, const Frags& cur, Frags& nxt) {
+    constexpr bool kSteady = decltype(STEADY)::value;
+    const bool more = kSteady || t + 1 < nt;
+    if constexpr (kSteady) wait_vmcnt<8 * (NSTAGE - 3)>();
+    else if (more) wait_stage(min(NSTAGE - 3, nt - 2 - t));
+    GMD_PHASE_FENCE();
+    if constexpr (kSteady) {
+      char* const fill = smem + ((t + NSTAGE - 1) % NSTAGE) * 2 * kS128TileBytes;
+      const char* const la = smem + ((t + 1) % NSTAGE) * 2 * kS128TileBytes;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        stage_one(j, t + NSTAGE - 1, fill);
+        read_one(nxt, 2 * j, la);
+        read_one(nxt, 2 * j + 1, la);
+      }
+      mfmas(cur);
+      constexpr int kPerGroup = DT == GMD_DT_BF16 ? 4 : 2;  // MFMAs per LDS-DMA instruction and pair of reads
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);          // one LDS-DMA instruction
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // two fragment reads
+        __builtin_amdgcn_sched_group_barrier(0x008, kPerGroup, 0);  // MFMAs
+      }
+    } else {
+      if (t + NSTAGE - 1 < nt) stage_both(t + NSTAGE - 1, smem + ((t + NSTAGE - 1) % NSTAGE) * 2 * kS128TileBytes);
+      if (more) read_frags(nxt, (t + 1) % NSTAGE);
+      mfmas(cur);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // Prologue: stages 0 .. NSTAGE-2 in flight, stage 0 landed and in registers.
+#pragma unroll
+  for (int j = 0; j < NSTAGE - 1; j++)
+    if (j < nt) stage_both(j, smem + j * 2 * kS128TileBytes);
+  wait_stage(min(NSTAGE - 2, nt - 1));
+  GMD_PHASE_FENCE();
+  Frags f0, f1;
+  read_frags(f0, 0);
+  using Steady = std::integral_constant<bool, true>;
+  using Tail = std::integral_constant<bool, false>;
+  int t = 0;
+  for (; t + NSTAGE < nt; t += 2) {  // both K-tiles of the pair have a stage to issue
+    ktile(Steady{}, t, f0, f1);
+    ktile(Steady{}, t + 1, f1, f0);
+  }
+  for (; t + 1 < nt; t += 2) {
+    ktile(Tail{}, t, f0, f1);
+    ktile(Tail{}, t + 1, f1, f0);
+  }
+  if (t < nt) ktile(Tail{}, t, f0, f1);
+
+  // Epilogue: B was the MFMA's first operand, so lane (fr, fq) holds, per 16 x 16 block, row fr and the four columns
+  // 4 fq .. 4 fq + 3.  Neighbouring 16-lane rows of two adjacent blocks swap halves (v_permlane16_swap), after which
+  // every lane holds eight consecutive columns of one block: 16-byte stores, each behind its bounds test.
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int row0 = tm * kS128 + wr * 64 + fr;
+  const int col0 = tn * kS128 + wc * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+  for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+    for (int nb = 0; nb < 4; nb += 2) {
+      const u32x2 x = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb], bf16x4));
+      const u32x2 y = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb + 1], bf16x4));
+      const u32x2 r0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+      const u32x2 r1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+      const u32x4 o = u32x4{r0.x, r1.x, r0.y, r1.y};
+      const int row = row0 + mb * 16, col = col0 + nb * 16;
+      if (row < M && col < N) __builtin_nontemporal_store(o, (u32x4*)(C + (size_t)row * ldc + col));  // N is a multiple of 8
+    }
+}
+
 constexpr int kVariantUnset = -2;
-constexpr int kVariantMax = 7;
+constexpr int kVariantMax = 8;
 int g_gemm_variant = kVariantUnset;
 
 int gemm_variant() {
@@ -1798,7 +2026,7 @@ int persistent_grid() {
 // Launch one instantiation with its dynamic LDS (128 KiB operand ring; MX-fp8 adds 8 KiB of scale ring).  The
 // opt-in attribute is per function and device; it is set again whenever the (kernel, device) pair differs from the
 // calling thread's previous launch.
-typedef void (*gemm_fn_t)(const char*, const char*, __bf16*, int, int, size_t, const uint32_t*, const uint32_t*);
+typedef void (*gemm_fn_t)(const char*, const char*, __bf16*, int, int, size_t, const uint32_t*, const uint32_t*, int);
 struct GemmArgs {
   const void *a, *b;
   void* c;
@@ -1806,18 +2034,21 @@ struct GemmArgs {
   size_t row_bytes;
   const uint32_t *sa, *sb;  // packed MX scales (MX-fp8 only)
   hipStream_t st;
+  int ldc = 0;  // C's row stride in elements; 0 = n
 };
 int launch_lds(gemm_fn_t kfn, int grid, int threads, int lds_bytes, const GemmArgs& g) {
-  thread_local gemm_fn_t last_fn = nullptr;
-  thread_local int last_dev = -1;
+  // (a decomposed GEMM alternates between two kernels: the last two pairs are remembered)
+  thread_local gemm_fn_t last_fn[2] = {nullptr, nullptr};
+  thread_local int last_dev[2] = {-1, -1};
   int dev = 0;
   GMD_HIP(hipGetDevice(&dev));
-  if (last_fn != kfn || last_dev != dev) {
+  if (!((last_fn[0] == kfn && last_dev[0] == dev) || (last_fn[1] == kfn && last_dev[1] == dev))) {
     GMD_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    last_fn = kfn;
-    last_dev = dev;
+    last_fn[1] = last_fn[0], last_dev[1] = last_dev[0];
+    last_fn[0] = kfn, last_dev[0] = dev;
   }
-  kfn<<<grid, threads, lds_bytes, g.st>>>((const char*)g.a, (const char*)g.b, (__bf16*)g.c, g.m, g.n, g.row_bytes, g.sa, g.sb);
+  kfn<<<grid, threads, lds_bytes, g.st>>>((const char*)g.a, (const char*)g.b, (__bf16*)g.c, g.m, g.n, g.row_bytes, g.sa, g.sb,
+                                          g.ldc ? g.ldc : g.n);
   GMD_HIP(hipGetLastError());
   return GMD_OK;
 }
@@ -1840,7 +2071,60 @@ int launch_gemm_t(const GemmArgs& g) {
   // (0, 1, 3, 4, 5 and 7) all stay on the K=32 one, for every shape.
   constexpr bool kFp8 = DT == GMD_DT_FP8;
   const int asked = gemm_variant();
-  const bool fp8_wide = kFp8 && (asked < 0 || asked > kVariantMax || asked == 2 || asked == 6);
+  const bool fp8_wide = kFp8 && (asked < 0 || asked > kVariantMax || asked == 2 || asked == 6 || asked == 8);
+  // Small problems and ragged edges (bf16 and unscaled fp8; MX-fp8 has no small-tile kernel).
+  // * Where the 256 x 256 tiles leave CUs idle, 128 x 128 tiles (schedule 8) fill them: taken when every CU gets at
+  //   most one small tile (2048^3: 64 large tiles on 256 CUs, or 256 small ones).  With several small tiles per CU the
+  //   kernel is bound by L2 bandwidth (a 128 x 128 tile has half the arithmetic intensity) and the large tiles win.
+  // * A matrix a little wider or taller than a whole number of large tiles costs a whole extra column or row of them
+  //   (4104 columns are 17 tile columns, the last 8 columns wide), and with it often a whole extra round over the
+  //   CUs.  The part that large tiles cover exactly then runs on them and the strips on small tiles: C's row stride
+  //   (ldc) stays the full width.  Taken when the model says it saves at least a tenth: a round of large tiles is 1,
+  //   a round of small ones 1 / (4 x 0.57) (measured at 8192^3).
+  // Schedule 8 asks for small tiles whatever the shape.
+  if constexpr (!kMx) {
+    const int cus = persistent_grid();
+    auto tiles128 = [](int m, int n) { return ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128); };
+    const int ldc = g.ldc ? g.ldc : g.n;
+    auto small = [&](const S128Region& r0, const S128Region& r1) -> int {
+      S128Args a;
+      a.r[0] = r0, a.r[1] = r1;
+      a.tiles0 = tiles128(r0.m, r0.n);
+      a.ldc = ldc;
+      a.row_bytes = g.row_bytes;
+      const int grid_s = a.tiles0 + (r1.m > 0 && r1.n > 0 ? tiles128(r1.m, r1.n) : 0);
+      thread_local int attr_dev = -1;
+      int dev = 0;
+      GMD_HIP(hipGetDevice(&dev));
+      if (attr_dev != dev) {
+        GMD_HIP(hipFuncSetAttribute((const void*)gemm_s128_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kS128LdsBytes));
+        attr_dev = dev;
+      }
+      gemm_s128_kernel<DT><<<grid_s, kS128Threads, kS128LdsBytes, g.st>>>(a);
+      GMD_HIP(hipGetLastError());
+      return GMD_OK;
+    };
+    const S128Region whole_matrix{(const char*)g.a, (const char*)g.b, (__bf16*)g.c, g.m, g.n}, none{nullptr, nullptr, nullptr, 0, 0};
+    const bool automatic = asked < 0 || asked > kVariantMax;
+    if (asked == 8 || (automatic && tiles128(g.m, g.n) <= cus)) return small(whole_matrix, none);
+    const int m_main = g.m / BM * BM, n_main = g.n / BN * BN;
+    if (automatic && !g.ldc && m_main > 0 && n_main > 0 && (m_main < g.m || n_main < g.n)) {
+      auto rounds = [&](int tiles) { return (double)((tiles + cus - 1) / cus); };
+      const int strip_tiles = (n_main < g.n ? tiles128(m_main, g.n - n_main) : 0) + (m_main < g.m ? tiles128(g.m - m_main, g.n) : 0);
+      const double whole = rounds(grid), split = rounds((m_main / BM) * (n_main / BN)) + rounds(strip_tiles) / (4 * 0.57);
+      if (split < 0.9 * whole) {
+        GemmArgs main = g;
+        main.m = m_main, main.n = n_main, main.ldc = g.n;
+        int rc = launch_gemm_t<DT>(main);  // full tiles: the pipelines proper
+        if (rc) return rc;
+        // right strip: rows [0, m_main), columns [n_main, n); bottom strip with the corner: rows [m_main, m), all columns
+        const S128Region right{(const char*)g.a, (const char*)g.b + (size_t)n_main * g.row_bytes, (__bf16*)g.c + n_main, m_main, g.n - n_main};
+        const S128Region bottom{(const char*)g.a + (size_t)m_main * g.row_bytes, (const char*)g.b, (__bf16*)g.c + (size_t)m_main * g.n, g.m - m_main, g.n};
+        if (n_main < g.n && m_main < g.m) return small(right, bottom);
+        return small(n_main < g.n ? right : bottom, none);
+      }
+    }
+  }
   if (!full_tiles || (!pairs && gemm_variant() != 0)) {
     if (fp8_wide)
       return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 1, false, true, true>, grid, kThreadsW4, kLdsBytes, g);
@@ -1907,7 +2191,7 @@ int launch_gemm_t(const GemmArgs& g) {
   // the only pipeline that carries MX scales, and since its epilogue stores whole rows from neighbouring lanes it is
   // ahead of the eight-wave kernels on bf16 and fp8 at 4096 (4-6 %), 8192 (0.5-1.6 %) and 16384 (0.6-1.1 %) alike.
   int variant = gemm_variant();
-  if (variant < 0 || variant > kVariantMax) variant = 2;
+  if (variant < 0 || variant >= kVariantMax) variant = 2;
   if (kMx && variant != 0 && variant != 6) variant = 2;
   if (!pairs) variant = 0;
   if (variant == 3 && !stream_ok) variant = 1;

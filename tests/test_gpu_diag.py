@@ -291,13 +291,13 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
                           (4352, 4352, 4 * kt), (4352, 4608, 10 * kt)]:  # 289 / 306 tiles: more than CUs, variant 3 streams
             G = _Gemm(diag, dev, m, n, k, dtype, seed=k)
             outs = {}
-            for variant in (0, 1, 2, 3, 4, 5, 6, 7, -1):
+            for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, -1):
                 diag.gemm_set_variant(variant)
                 c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
                 G.launch(c)
                 torch.cuda.synchronize()
                 outs[variant] = c
-                if variant in (1, 2, 3, 6, 7):  # 4 and 5 differ from 1 in the epilogue only
+                if variant in (1, 2, 3, 6, 7, 8):  # 4 and 5 differ from 1 in the epilogue only
                     c2 = torch.empty_like(c)
                     for _ in range(20):
                         G.launch(c2)
@@ -305,28 +305,32 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
                     assert torch.equal(c2, c), (variant, m, n, k)
             # Unscaled fp8: the default, 2 and 6 run on the K=128 instruction, which adds the same products up in another
             # order; 7 is schedule 2 on the K=32 instruction.  Each group is identical within itself.
-            wide = (2, 6, -1) if dtype == "fp8" else ()
-            for variant in (1, 2, 3, 4, 5, 6, 7, -1):
+            wide = (2, 6, 8, -1) if dtype == "fp8" else ()
+            for variant in (1, 2, 3, 4, 5, 6, 7, -1) + (() if dtype == "mxfp8" else (8,)):
                 assert torch.equal(outs[2 if variant in wide else 0], outs[variant]), (variant, m, n, k)
             if wide:
                 ref = G.ref()
                 for v in (0, 2):
                     assert ((outs[v].float() - ref).abs().max() / ref.abs().max()).item() < 6e-3, (v, m, n, k)
         with pytest.raises(diag.DiagError):
-            diag.gemm_set_variant(9)
+            diag.gemm_set_variant(10)
     finally:
         diag.gemm_set_variant(-1)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 @pytest.mark.parametrize("shape", [(8, 8, 1), (264, 248, 3), (1000, 520, 5), (256, 256, 1), (4000, 4104, 2), (2048, 24, 7),
-                                   (16, 3000, 4)])
+                                   (16, 3000, 4), (4104, 4000, 3), (4360, 4360, 4), (2048, 2048, 6), (4352, 4360, 2)])
 def test_gemm_takes_the_operators_shape(diag, dev, dtype, shape):
     """M and N in multiples of 8 (tiles that reach beyond the matrix fetch its last rows again and store behind a
     bounds test), any number of K-tiles (an odd count is completed by a K-tile of zeros).  The output is compared with
     fp32 everywhere, a guard band behind C must stay untouched, and every schedule that can be asked for gives the
     same bits (they all route to the general instantiation of the four-wave kernel; with full tiles schedule 0 runs its
-    own loop).  Unscaled fp8 has two such instantiations, one per MFMA instruction (K=128: default, 2, 6; K=32: the rest)."""
+    own loop).  Unscaled fp8 has two such instantiations, one per MFMA instruction (K=128: default, 2, 6, 8; K=32: the rest).
+    The default also covers small problems with 128 x 128 tiles (2048 x 2048) and splits a matrix that is a little wider
+    or taller than a whole number of 256 x 256 tiles into a part the large tiles cover exactly and strips of small ones
+    (4000 x 4104: right strip and bottom strip; 4104 x 4000; 4360 x 4360; 4352 x 4360: right strip only): the same bits
+    as one launch of the general kernel (schedule 2) and of the small-tile kernel alone (schedule 8)."""
     m, n, kt = shape
     k = kt * (64 if dtype == "bf16" else 128)
     G = _Gemm(diag, dev, m, n, k, dtype, seed=m + n + k)
@@ -342,12 +346,12 @@ def test_gemm_takes_the_operators_shape(diag, dev, dtype, shape):
     assert (buf[m * n:] == 7.0).all()
     narrow = None
     try:
-        for variant in (0, 1, 2, 3, 6, 7):
+        for variant in (0, 1, 2, 3, 6, 7, 8):
             diag.gemm_set_variant(variant)
             c2 = torch.empty_like(c)
             G.launch(c2)
             torch.cuda.synchronize()
-            if dtype == "fp8" and variant not in (2, 6):  # on the K=32 instruction: another order of summation
+            if dtype == "fp8" and variant not in (2, 6, 8):  # on the K=32 instruction: another order of summation
                 err = (c2.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
                 assert err < 6e-3, (variant, err)
                 assert narrow is None or torch.equal(c2, narrow), variant
