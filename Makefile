@@ -26,7 +26,7 @@ BINS     := gpumon gpumon-exporter gpumon-hostengine gpumon-pod-exporter
 DIAG_HIP := diag/hip/hbm_stream.hip diag/hip/memtest.hip diag/hip/mfma_gemm.hip diag/hip/diag_api.hip \
             diag/rccl/rccl_sweep.hip diag/hip/link_test.hip
 DIAG_OBJ := $(DIAG_HIP:%.hip=$(BUILD)/obj/%.o)
-HIPFLAGS += --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Idiag -Wno-unused-result
+HIPFLAGS += --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Idiag -Wno-unused-result -Wno-inline-asm
 
 .PHONY: all core bins diag prof test tsan asan clean
 all: core bins
@@ -53,7 +53,7 @@ diag: $(BUILD)/libgpumon_diag.so $(BUILD)/bin/gpumon-diag
 $(BUILD)/libgpumon_diag.so: $(DIAG_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -ldl
 
-$(BUILD)/bin/gpumon-diag: cmd/gpumon-diag.cc cmd/cli_common.h diag/gpumon_diag.h $(BUILD)/libgpumon_diag.so $(BUILD)/libgpumon.so
+$(BUILD)/bin/gpumon-diag: cmd/gpumon-diag.cc cmd/cli_common.h cmd/diag_expect.h diag/gpumon_diag.h $(BUILD)/libgpumon_diag.so $(BUILD)/libgpumon.so
 	@mkdir -p $(dir $@)
 	$(CXX) $(CXXFLAGS) -fvisibility=default -o $@ $< -L$(BUILD) -lgpumon_diag -lgpumon \
 	    -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath-link,$(ROCM)/lib $(LDFLAGS)

@@ -124,3 +124,15 @@ func getProcessInfo(g GroupHandle, pid uint) ([]ProcessInfo, error) {
 	}
 	return out, nil
 }
+
+// ProcessSource names where the process list of a GPU comes from on this host:
+// "kfd" (the device library's table), "fdinfo" (per-client DRM statistics under
+// /proc), "open-files" (holders of the render node: memory and engine time are
+// then unknown), "fake" or "none".
+func ProcessSource(gpu uint) (string, error) {
+	var buf [32]C.char
+	if err := check("process source", C.gm_process_source(C.uint32_t(gpu), &buf[0], C.size_t(len(buf)))); err != nil {
+		return "", err
+	}
+	return C.GoString(&buf[0]), nil
+}

@@ -505,6 +505,15 @@ void Exporter::render_self(std::string* out) {
     gauge("gpumon_engine_sample_cycles_total", "Sample cycles completed.", (double)in.sample_cycles, "counter");
     gauge("gpumon_engine_backend_errors_total", "Device-library calls that failed.", (double)in.backend_errors, "counter");
   }
+  // Where each GPU's process list comes from on this host; "open-files" means per-process memory is unknown.
+  std::string src_lines;
+  for (uint32_t g : gpus_) {
+    std::string src;
+    if (engine_->process_source(g, &src) == GM_ST_OK) src_lines += strprintf("gpumon_engine_process_source{gpu=\"%u\",source=\"%s\"} 1\n", g, src.c_str());
+  }
+  if (!src_lines.empty())
+    *out += "# HELP gpumon_engine_process_source Source of the per-GPU process list: kfd, fdinfo, open-files, fake or none.\n"
+            "# TYPE gpumon_engine_process_source gauge\n" + src_lines;
   gauge("gpumon_exporter_render_duration_seconds", "Wall time of the previous text render.", (double)last_render_us_ / 1e6);
   gauge("gpumon_exporter_sweeps_total", "File sweeps published.", (double)sweeps_, "counter");
   gauge("gpumon_exporter_scrapes_total", "HTTP scrapes served.", (double)scrapes_, "counter");

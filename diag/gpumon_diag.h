@@ -169,7 +169,7 @@ GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double s
 typedef struct {
   int32_t device, dtype, m, n, k;
   int32_t verify;       /* reference comparison of the first launch + checksums */
-  int32_t check_every;  /* checksum every Nth launch; <= 0: 4 */
+  int32_t check_every;  /* checksum every Nth launch; <= 0: 8 */
   double seconds;
 } gmd_gemm_stress_config_t;
 GMD_API int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* out);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void verify_kernel(const u64x2* __restrict_
 // goes through the addresses in both directions).  16 bytes read and 16 bytes written per lane.
 template <uint32_t PAT, bool INV, bool DOWN>
 __global__ __launch_bounds__(kBlock) void march_kernel(u64x2* __restrict__ buf, uint64_t n2, uint64_t base_word, uint64_t seed, VerifyOut* out) {
-  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n2) return;
   if (DOWN) i = n2 - 1 - i;
   const u64x2 v = __builtin_nontemporal_load(buf + i);
@@ -206,13 +206,16 @@ void launch_march(u64x2* buf, uint64_t n2, uint64_t base_word, uint32_t pattern,
   for (uint64_t k = 0; k < launches; k++) {
     const uint64_t off = (down ? launches - 1 - k : k) * kPerLaunch;
     const uint64_t n = std::min(kPerLaunch, n2 - off);
-    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    // One wave per workgroup and no cap on workgroups per CU, the shape of the copy stream: a kernel that reads and
+    // writes wants many small workgroups in flight (6.05 TB/s; 5.3 in the pure store's shape of 256 lanes, four per CU).
+    constexpr unsigned blk = 64, lds = 0;
+    const unsigned grid = (unsigned)((n + blk - 1) / blk);
 #define CALL(P)                                                                                                          \
   do {                                                                                                                   \
-    if (!inv && !down) march_kernel<P, false, false><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed, out); \
-    else if (inv && down) march_kernel<P, true, true><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed, out); \
-    else if (inv) march_kernel<P, true, false><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed, out);       \
-    else march_kernel<P, false, true><<<grid, kBlock, kFillLdsBytes, st>>>(buf + off, n, base_word + 2 * off, seed, out);                \
+    if (!inv && !down) march_kernel<P, false, false><<<grid, blk, lds, st>>>(buf + off, n, base_word + 2 * off, seed, out); \
+    else if (inv && down) march_kernel<P, true, true><<<grid, blk, lds, st>>>(buf + off, n, base_word + 2 * off, seed, out); \
+    else if (inv) march_kernel<P, true, false><<<grid, blk, lds, st>>>(buf + off, n, base_word + 2 * off, seed, out);       \
+    else march_kernel<P, false, true><<<grid, blk, lds, st>>>(buf + off, n, base_word + 2 * off, seed, out);                \
   } while (0)
     GMD_FOR_PATTERN(pattern, CALL)
 #undef CALL

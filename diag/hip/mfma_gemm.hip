@@ -2321,7 +2321,7 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
   memset(out, 0, sizeof *out);
   const int device = cfg->device, dtype = cfg->dtype, m = cfg->m, n = cfg->n, k = cfg->k, verify = cfg->verify;
   const double seconds = cfg->seconds;
-  const int check_every = cfg->check_every > 0 ? cfg->check_every : 4;
+  const int check_every = cfg->check_every > 0 ? cfg->check_every : 8;
   const bool fp8 = dtype == GMD_DT_FP8 || dtype == GMD_DT_MXFP8;
   const bool mx = dtype == GMD_DT_MXFP8;
   if (dtype != GMD_DT_BF16 && !fp8) return GMD_ERR_BADPARAM;

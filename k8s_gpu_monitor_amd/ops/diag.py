@@ -191,7 +191,7 @@ class GemmStressConfig(C.Structure):
 
 def gemm_stress(dtype="bf16", m=8192, n=8192, k=8192, seconds=2.0, verify=True, device=0, check_every=0):
     """GEMM soak: back-to-back launches, the first compared with an fp32 reference, the checksum of every
-    `check_every`-th result (0 = the default, 4) compared with the first one's."""
+    `check_every`-th result (0 = the default, 8) compared with the first one's."""
     L = _lib()
     L.gmd_gemm_stress_run.argtypes = [C.POINTER(GemmStressConfig), C.POINTER(MfmaResult)]
     cfg = GemmStressConfig(device, DTYPES[dtype], m, n, k, int(verify), check_every, seconds)

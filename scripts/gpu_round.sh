@@ -33,6 +33,11 @@ for s in $STEPS; do
     diag)
       step diag_run2 600 build/bin/gpumon-diag run -r 2
       step diag_rccl 300 build/bin/gpumon-diag rccl --max-bytes 256M --factor 16
+      step diag_links 120 build/bin/gpumon-diag links
+      ;;
+    soak)
+      # the long suite on one GPU: whole-HBM sweep with march, 60 s soak with the matrix-pipe counter next to it
+      step diag_run3 900 build/bin/gpumon-diag run -r 3 --mfma-counters --publish "$OUT/diag_run3_report.json"
       ;;
     scrape)
       # exporter cost at 1 s resolution: real device library, then the same binary while the GPU soaks
@@ -62,15 +67,18 @@ for s in $STEPS; do
       D="$PWD/build/bin/gpumon-diag"
       for target in "gemm_bf16:gemm --dtype bf16 --seconds 0.05 --no-telemetry" "gemm_fp8:gemm --dtype fp8 --seconds 0.05 --no-telemetry" \
                     "gemm_mxfp8:gemm --dtype mxfp8 --seconds 0.05 --no-telemetry" \
-                    "hbm:hbm --bytes 2G --iters 2" "memtest:memtest --bytes 4G --patterns random,address"; do
+                    "hbm:hbm --bytes 2G --iters 2 --no-expect" "memtest:memtest --bytes 4G --chunk 4G --patterns random,address --march --no-expect"; do
         name=${target%%:*}; args=${target#*:}
+        buf=""  # buffer size of the streaming targets, for the expected-bytes columns
+        [ "$name" = hbm ] && buf=2147483648
+        [ "$name" = memtest ] && buf=4294967296
         case " ${PMC_TARGETS:-gemm_bf16 gemm_fp8 gemm_mxfp8 hbm memtest} " in *" $name "*) ;; *) continue ;; esac
         step "pmc_sq_$name" 120 timeout -s KILL 100 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_UNALIGNED_STALL \
           --output-format csv -d "$PWD/$OUT/pmc_sq_$name" -o p -- "$D" $args
         step "pmc_rd_$name" 120 timeout -s KILL 100 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$PWD/$OUT/pmc_rd_$name" -o p -- "$D" $args
         step "pmc_wr_$name" 120 timeout -s KILL 100 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$PWD/$OUT/pmc_wr_$name" -o p -- "$D" $args
         for pass in sq rd wr; do
-          python scripts/prof_summary.py "$OUT/pmc_${pass}_$name" "$OUT/pmc_${pass}_$name.md" "$pass counters: gpumon-diag $name" > /dev/null
+          python scripts/prof_summary.py "$OUT/pmc_${pass}_$name" "$OUT/pmc_${pass}_$name.md" "$pass counters: gpumon-diag $name" $buf > /dev/null
         done
       done
       ;;

@@ -7,7 +7,12 @@ The register and LDS table comes from the code objects of the in-tree libraries
 columns show 0 bytes of LDS for LDS requested at launch and no accumulator
 registers.  Kernels of other libraries keep rocprofv3's figures, marked as such.
 
-usage: prof_summary.py <dir-with-csv> <out.md> [title]
+FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes, so a wide coalesced
+stream (16 bytes per lane, every kernel here) shows HALF the bytes it fetched; WRITE_SIZE is exact for 16-byte-per-lane
+stores.  With a buffer size the report adds the bytes those counters stand for next to what the kernel is known to
+move (reads / writes as multiples of the buffer: copy 1 / 1, triad 2 / 1, ...).
+
+usage: prof_summary.py <dir-with-csv> <out.md> [title] [buffer-bytes]
 """
 import csv
 import glob
@@ -36,8 +41,21 @@ def code_object_table():
         return {}
 
 
+# (reads, writes) of the streaming kernels as multiples of the buffer the command was given
+TRAFFIC = [("onepass_kernel<0", 1, 1), ("onepass_kernel<1", 1, 1), ("onepass_kernel<2", 2, 1), ("onepass_kernel<3", 2, 1),
+           ("onepass_kernel<5", 0, 1), ("read_kernel", 1, 0), ("fill_kernel", 0, 1), ("verify_kernel", 1, 0), ("march_kernel", 1, 1)]
+
+
+def expected_traffic(kernel, buffer_bytes):
+    for prefix, r, w in TRAFFIC:
+        if kernel.startswith(prefix):
+            return r * buffer_bytes, w * buffer_bytes
+    return None
+
+
 def main():
     src, out = sys.argv[1], sys.argv[2]
+    buffer_bytes = int(float(sys.argv[4])) if len(sys.argv) > 4 else 0
     ours = code_object_table()
     title = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(src.rstrip("/"))
     lines = [f"# {title}", ""]
@@ -74,7 +92,23 @@ def main():
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].values()))[:20]:
             n = max(1, len(calls[k]))
             lines.append(f"| `{k}` | {n} | " + " | ".join(f"{v.get(c, 0) / n:.4g}" for c in counters) + " |")
-        lines += ["", "(counter values are per-dispatch means)", "",
+        lines += ["", "(counter values are per-dispatch means)", ""]
+        if "FETCH_SIZE" in counters or "WRITE_SIZE" in counters:
+            lines += ["FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes: a 16-byte-per-lane",
+                      "stream shows half of what it fetched, so bytes read = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact.", ""]
+            if buffer_bytes:
+                lines += [f"With {buffer_bytes / 2**30:.2f} GiB per buffer:", "",
+                          "| kernel | bytes read (2 x FETCH_SIZE KiB) | expected | bytes written (WRITE_SIZE KiB) | expected |", "|---|---:|---:|---:|---:|"]
+                for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].values())):
+                    exp = expected_traffic(k, buffer_bytes)
+                    if not exp:
+                        continue
+                    n = max(1, len(calls[k]))
+                    rd = f"{2 * 1024 * v['FETCH_SIZE'] / n / 2**30:.3f} GiB" if "FETCH_SIZE" in v else "-"
+                    wr = f"{1024 * v['WRITE_SIZE'] / n / 2**30:.3f} GiB" if "WRITE_SIZE" in v else "-"
+                    lines.append(f"| `{k}` | {rd} | {exp[0] / 2**30:.3f} GiB | {wr} | {exp[1] / 2**30:.3f} GiB |")
+                lines.append("")
+        lines += [
                   "| kernel | VGPR (all) | of which AGPR | SGPR | VGPR spills | LDS bytes (static + at launch) | workgroup | grid | source |",
                   "|---|---:|---:|---:|---:|---:|---:|---:|---|"]
         for k, r in regs.items():

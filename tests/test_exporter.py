@@ -265,6 +265,8 @@ def test_amd_extras_and_self_metrics(engine2):
     for name in ("gpumon_engine_cpu_percent", "gpumon_engine_memory_kb", "gpumon_exporter_render_duration_seconds",
                  "gpumon_engine_sample_cycle_seconds"):
         assert name in fams and len(fams[name].samples) == 1
+    # where the process list comes from is visible per GPU (on a host without the KFD table: fdinfo or open-files)
+    assert {(l["gpu"], l["source"]) for l, _ in fams["gpumon_engine_process_source"].samples} == {("0", "fake"), ("1", "fake")}
     # the contract families are untouched by the extras
     assert fams["dcgm_sm_clock"].help == "SM clock frequency (in MHz)."
 
