@@ -16,7 +16,7 @@ CXXFLAGS  += -std=c++17 $(OPT) -g -fPIC -Wall -Wextra -Wno-unused-parameter -Wno
 LDFLAGS   += -pthread -ldl $(SAN)
 
 CORE_SRC := core/common/util.cc core/common/json.cc core/fields.cc \
-            core/backend/fake_backend.cc core/backend/amdsmi_backend.cc core/backend/replicate_backend.cc core/backend/procscan.cc \
+            core/backend/fake_backend.cc core/backend/amdsmi_backend.cc core/backend/replicate_backend.cc core/backend/procscan.cc core/backend/metrics_table.cc \
             core/engine/engine.cc core/engine/health.cc core/engine/policy.cc core/engine/accounting.cc \
             core/rpc/wire.cc core/rpc/server.cc core/rpc/client.cc \
             core/exporter/http.cc core/exporter/exporter.cc core/exporter/podmap.cc core/exporter/kubelet.cc core/exporter/diag_results.cc core/prof/prof_child.cc \

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -28,6 +29,7 @@
 #include "../prof/prof_child.h"
 #include "../prof/prof_counters.h"
 #include "backend.h"
+#include "metrics_table.h"
 #include "procscan.h"
 
 namespace gpumon {
@@ -130,9 +132,41 @@ uint8_t blank_reason(amdsmi_status_t st) {
   }
 }
 
+constexpr int64_t kTableRecheckUs = 300ll * 1000000;  // the direct metrics-table decoding is held against the library's this often
+
 template <typename T>
 bool valid(T v) {
   return v != (T)~(T)0;
+}
+
+static_assert(kMtXcp == AMDSMI_MAX_NUM_XCP && kMtXcc == AMDSMI_MAX_NUM_XCC && kMtHbm == AMDSMI_NUM_HBM_INSTANCES &&
+                  kMtVcn == AMDSMI_MAX_NUM_VCN && kMtGfxClks == AMDSMI_MAX_NUM_GFX_CLKS && kMtClks == AMDSMI_MAX_NUM_CLKS &&
+                  kMtLinks == AMDSMI_MAX_NUM_XGMI_LINKS,
+              "MetricsTable mirrors the array bounds of amdsmi_gpu_metrics_t");
+
+// The members the sampler consumes, out of the library's all-versions struct.
+void from_library(const amdsmi_gpu_metrics_t& a, MetricsTable* m) {
+  metrics_table_clear(m);
+#define CP(name) m->name = a.name
+  CP(temperature_edge); CP(temperature_hotspot); CP(temperature_mem); CP(temperature_vrgfx); CP(temperature_vrsoc); CP(temperature_vrmem);
+  CP(average_gfx_activity); CP(average_umc_activity); CP(average_mm_activity); CP(average_socket_power); CP(current_socket_power);
+  CP(current_gfxclk); CP(current_socclk); CP(current_uclk); CP(current_vclk0); CP(current_dclk0);
+  CP(pcie_link_width); CP(pcie_link_speed); CP(xgmi_link_width); CP(xgmi_link_speed); CP(num_partition);
+  CP(pcie_nak_sent_count_acc); CP(pcie_nak_rcvd_count_acc); CP(energy_accumulator); CP(firmware_timestamp);
+  CP(pcie_bandwidth_inst); CP(pcie_l0_to_recov_count_acc); CP(pcie_replay_count_acc); CP(accumulation_counter);
+  CP(prochot_residency_acc); CP(ppt_residency_acc); CP(socket_thm_residency_acc); CP(vr_thm_residency_acc); CP(hbm_thm_residency_acc);
+#undef CP
+#define CPA(name) memcpy(m->name, a.name, sizeof m->name); static_assert(sizeof m->name == sizeof a.name, #name)
+  CPA(temperature_hbm); CPA(current_gfxclks); CPA(current_socclks); CPA(current_vclk0s); CPA(current_dclk0s); CPA(vcn_activity);
+  CPA(xgmi_link_status); CPA(xgmi_read_data_acc); CPA(xgmi_write_data_acc);
+#undef CPA
+  for (int p = 0; p < kMtXcp; p++)
+    for (int x = 0; x < kMtXcc; x++) {
+      m->xcp_stats[p].gfx_busy_inst[x] = a.xcp_stats[p].gfx_busy_inst[x];
+      m->xcp_stats[p].gfx_below_host_limit_acc[x] = a.xcp_stats[p].gfx_below_host_limit_acc[x];
+      m->xcp_stats[p].gfx_below_host_limit_total_acc[x] = a.xcp_stats[p].gfx_below_host_limit_total_acc[x];
+      m->xcp_stats[p].gfx_low_utilization_acc[x] = a.xcp_stats[p].gfx_low_utilization_acc[x];
+    }
 }
 
 struct Dev {
@@ -159,6 +193,10 @@ struct Dev {
   uint64_t cper_cursor = 0;
   bool cper_ok = true, cper_primed = false;
   bool violation_checked = false;
+  // Direct reads of the driver's metrics table (metrics_table.h): the kept descriptor, -1 while the library reads.
+  int table_fd = -1;
+  int64_t table_checked_mono = 0;   // last comparison with the library's decoding
+  std::string table_note;           // why direct reads are off, for metrics_table_source()
   // CU occupancy comes from the KFD process table, which costs a walk over /proc: read it at most once a
   // second however fast the profiling fields are watched, and not at all where the table is not readable.
   int64_t occupancy_read_mono = 0;
@@ -266,6 +304,7 @@ class AmdSmiBackend : public Backend {
     prof_child_.reset();
     prof_tried_ = false;  // a later init maps the plugin's agents onto the new device table
     inited_ = false;
+    close_tables(devs_);
     devs_.clear();
     // The library stays mapped: amdsmi keeps thread-local state that outlives shut_down.
   }
@@ -320,6 +359,12 @@ class AmdSmiBackend : public Backend {
     if (sources & SRC_BAD_PAGES) any_ok |= sample_bad_pages(d, out);
     if (sources & SRC_PERF) any_ok |= sample_perf(d, out);
     return any_ok ? GM_ST_OK : GM_ST_GENERIC_ERROR;
+  }
+
+  std::string metrics_table_source(uint32_t gpu) override {
+    if (gpu >= devs_.size()) return "n/a";
+    const Dev& d = devs_[gpu];
+    return d.table_fd >= 0 ? "direct" : d.table_note.empty() ? "library" : "library: " + d.table_note;
   }
 
   const char* process_source(uint32_t gpu) override {
@@ -704,6 +749,7 @@ class AmdSmiBackend : public Backend {
       read_static(found[i]);
     }
     devs_.swap(found);
+    close_tables(found);  // the table before this enumeration
     GM_LOGI("amdsmi: %zu GPU(s)", devs_.size());
     return GM_ST_OK;
   }
@@ -845,13 +891,93 @@ class AmdSmiBackend : public Backend {
     }
     // Engine support: CDNA-class (gfx9xx) devices with a metrics table.
     s.supported = !s.uuid.empty() && !s.pci_bdf.empty();
+    open_table(d);
+  }
+
+  static void close_tables(std::vector<Dev>& v) {
+    for (auto& d : v)
+      if (d.table_fd >= 0) close(d.table_fd), d.table_fd = -1;
+  }
+
+  // One comparison of the direct decoding with the library's, on bytes that did not change under the library's
+  // read: 1 = equal, 0 = different (why), -1 = no clean pair this time.
+  int compare_with_library(Dev& d, std::string* why) {
+    uint8_t r0[4096], r1[4096];
+    for (int attempt = 0; attempt < 8; attempt++) {
+      const ssize_t n0 = pread(d.table_fd, r0, sizeof r0, 0);
+      amdsmi_gpu_metrics_t a;
+      memset(&a, 0xff, sizeof a);
+      if (api_.amdsmi_get_gpu_metrics_info(d.h, &a) != AMDSMI_STATUS_SUCCESS) { *why = "the library's read failed"; return -1; }
+      const ssize_t n1 = pread(d.table_fd, r1, sizeof r1, 0);
+      if (n0 <= 0 || n0 != n1) { *why = "short read"; return 0; }
+      if (memcmp(r0, r1, (size_t)n0)) continue;  // the firmware refreshed the table in between
+      MetricsTable mine, theirs;
+      if (!metrics_table_decode(r0, (size_t)n0, &mine, why)) return 0;
+      from_library(a, &theirs);
+      *why = metrics_table_diff(mine, theirs);
+      return why->empty() ? 1 : 0;
+    }
+    *why = "the table kept changing";
+    return -1;
+  }
+
+  void open_table(Dev& d) {
+    const char* mode = getenv("GPUMON_METRICS_TABLE");  // auto (default) | library
+    if (mode && !strcmp(mode, "library")) { d.table_note = "switched off by GPUMON_METRICS_TABLE"; return; }
+    if (d.st.pci_bdf.empty()) { d.table_note = "no PCI address"; return; }
+    const std::string path = "/sys/bus/pci/devices/" + d.st.pci_bdf + "/gpu_metrics";
+    d.table_fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (d.table_fd < 0) { d.table_note = path + ": " + strerror(errno); return; }
+    std::string why;
+    const int same = compare_with_library(d, &why);
+    if (same != 1) {
+      d.table_note = same ? "not checked: " + why : "differs from the library: " + why;
+      close(d.table_fd);
+      d.table_fd = -1;
+      GM_LOGI("amdsmi: gpu %u metrics table through the library (%s)", d.st.index, d.table_note.c_str());
+      return;
+    }
+    d.table_checked_mono = monotonic_us();
+    GM_LOGI("amdsmi: gpu %u metrics table read directly from %s", d.st.index, path.c_str());
+  }
+
+  // The table for one sample: the direct read where it is on and healthy, else the library.
+  bool read_table(Dev& d, MetricsTable* m, amdsmi_status_t* rc) {
+    *rc = AMDSMI_STATUS_SUCCESS;
+    if (d.table_fd >= 0) {
+      const int64_t now = monotonic_us();
+      std::string why;
+      if (now - d.table_checked_mono > kTableRecheckUs) {
+        d.table_checked_mono = now;
+        if (compare_with_library(d, &why) == 0) {
+          GM_LOGW("amdsmi: gpu %u direct metrics table no longer matches the library (%s): back to the library", d.st.index, why.c_str());
+          d.table_note = "differs from the library: " + why;
+          close(d.table_fd);
+          d.table_fd = -1;
+        }
+      }
+      if (d.table_fd >= 0) {
+        uint8_t raw[4096];
+        const ssize_t n = pread(d.table_fd, raw, sizeof raw, 0);
+        if (n > 0 && metrics_table_decode(raw, (size_t)n, m, &why)) return true;
+        GM_LOGW("amdsmi: gpu %u direct metrics table read failed (%s): back to the library", d.st.index, n > 0 ? why.c_str() : strerror(errno));
+        d.table_note = n > 0 ? why : std::string("read: ") + strerror(errno);
+        close(d.table_fd);
+        d.table_fd = -1;
+      }
+    }
+    amdsmi_gpu_metrics_t a;
+    memset(&a, 0xff, sizeof a);
+    *rc = api_.amdsmi_get_gpu_metrics_info(d.h, &a);
+    if (*rc != AMDSMI_STATUS_SUCCESS) return false;
+    from_library(a, m);
+    return true;
   }
 
   bool sample_metrics(Dev& d, uint32_t sources, Sample* out) {
-    amdsmi_gpu_metrics_t m;
-    memset(&m, 0xff, sizeof m);
-    amdsmi_status_t rc = api_.amdsmi_get_gpu_metrics_info(d.h, &m);
-    if (rc != AMDSMI_STATUS_SUCCESS) {
+    MetricsTable m;
+    amdsmi_status_t rc;
+    if (!read_table(d, &m, &rc)) {
       out->blank_untouched(sources & (SRC_METRICS | SRC_VIOLATION | SRC_ENERGY | SRC_PROF), blank_reason(rc));
       return false;
     }

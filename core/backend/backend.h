@@ -148,6 +148,9 @@ class Backend {
   // Where the last processes() answer for this GPU came from: "kfd" (the device library's table), "fdinfo"
   // (the kernel's per-file DRM statistics), "open-files" (holders of the render node, no figures), "fake", "none".
   virtual const char* process_source(uint32_t gpu) { (void)gpu; return "none"; }
+  // How the bulk metrics table of this GPU is read: "direct" (the backend's own read of the driver's file),
+  // "library", with a reason after a colon where direct reads were refused; "n/a" for backends without one.
+  virtual std::string metrics_table_source(uint32_t gpu) { (void)gpu; return "n/a"; }
   virtual gm_status_t peer_link(uint32_t gpu, uint32_t peer, PeerLink* out) = 0;
   // Every physical xGMI link of the GPU, in the index order of the per-link telemetry fields.
   virtual gm_status_t xgmi_links(uint32_t gpu, std::vector<XgmiLink>* out) {

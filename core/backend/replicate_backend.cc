@@ -43,6 +43,7 @@ class ReplicateBackend : public Backend {
     return inner_->processes(gpu % real_, out);
   }
   const char* process_source(uint32_t gpu) override { return real_ ? inner_->process_source(gpu % real_) : "none"; }
+  std::string metrics_table_source(uint32_t gpu) override { return real_ ? inner_->metrics_table_source(gpu % real_) : "n/a"; }
   gm_status_t peer_link(uint32_t gpu, uint32_t peer, PeerLink* out) override {
     if (!real_ || gpu >= device_count() || peer >= device_count() || gpu == peer) return GM_ST_BADPARAM;
     if (gpu % real_ == peer % real_) return GM_ST_NOT_SUPPORTED;  // a GPU and its own replica

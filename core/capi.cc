@@ -11,6 +11,7 @@
 
 extern char** environ;
 
+#include "backend/metrics_table.h"
 #include "backend/procscan.h"
 #include "common/util.h"
 #include "engine/engine.h"
@@ -509,6 +510,27 @@ gm_status_t gm_proc_scan(const char* proc_root, const char* pci_bdf, int render_
     gpumon::copy_str(o.name, scan.procs[i].name);
   }
   return *n > capn ? GM_ST_INSUFFICIENT_SIZE : GM_ST_OK;
+}
+gm_status_t gm_metrics_table_decode(const void* raw, size_t n, char* json, size_t cap) {
+  if (!raw || !json || !cap) return GM_ST_BADPARAM;
+  gpumon::MetricsTable m;
+  std::string why;
+  if (!gpumon::metrics_table_decode(static_cast<const uint8_t*>(raw), n, &m, &why)) {
+    snprintf(json, cap, "%s", why.c_str());
+    return GM_ST_NOT_SUPPORTED;
+  }
+  const std::string j = gpumon::metrics_table_json(m);
+  if (j.size() + 1 > cap) return GM_ST_INSUFFICIENT_SIZE;
+  memcpy(json, j.c_str(), j.size() + 1);
+  return GM_ST_OK;
+}
+gm_status_t gm_metrics_table_source(uint32_t gpu, char* buf, size_t cap) {
+  REQUIRE_ENGINE();
+  if (!buf || !cap) return GM_ST_BADPARAM;
+  std::string s;
+  gm_status_t st = e->metrics_table_source(gpu, &s);
+  if (st == GM_ST_OK) snprintf(buf, cap, "%s", s.c_str());
+  return st;
 }
 gm_status_t gm_device_mode(uint32_t gpu, gm_device_mode_t* out) {
   REQUIRE_ENGINE();

@@ -58,6 +58,7 @@ class Engine {
   virtual gm_status_t device_processes(uint32_t gpu, std::vector<gm_process_t>* out) = 0;
   // Where the process list of this GPU comes from on this host ("kfd", "fdinfo", "open-files", "fake", "none").
   virtual gm_status_t process_source(uint32_t gpu, std::string* out) = 0;
+  virtual gm_status_t metrics_table_source(uint32_t gpu, std::string* out) = 0;
   virtual gm_status_t device_mode(uint32_t gpu, gm_device_mode_t* out) = 0;
 
   virtual gm_status_t health_set(gm_group_t g, uint32_t systems) = 0;
@@ -144,6 +145,7 @@ class LocalEngine : public Engine {
   gm_status_t device_status(uint32_t gpu, gm_device_status_t* out) override;
   gm_status_t device_processes(uint32_t gpu, std::vector<gm_process_t>* out) override;
   gm_status_t process_source(uint32_t gpu, std::string* out) override;
+  gm_status_t metrics_table_source(uint32_t gpu, std::string* out) override;
   gm_status_t device_mode(uint32_t gpu, gm_device_mode_t* out) override;
   gm_status_t health_set(gm_group_t g, uint32_t systems) override;
   gm_status_t health_get(gm_group_t g, uint32_t* systems) override;

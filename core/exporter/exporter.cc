@@ -514,6 +514,16 @@ void Exporter::render_self(std::string* out) {
   if (!src_lines.empty())
     *out += "# HELP gpumon_engine_process_source Source of the per-GPU process list: kfd, fdinfo, open-files, fake or none.\n"
             "# TYPE gpumon_engine_process_source gauge\n" + src_lines;
+  // Whether the bulk metrics table is read from the driver's file directly (1) or through the device library (0).
+  std::string table_lines;
+  for (uint32_t g : gpus_) {
+    std::string src;
+    if (engine_->metrics_table_source(g, &src) == GM_ST_OK && src != "n/a")
+      table_lines += strprintf("gpumon_engine_metrics_table_direct{gpu=\"%u\"} %d\n", g, src == "direct" ? 1 : 0);
+  }
+  if (!table_lines.empty())
+    *out += "# HELP gpumon_engine_metrics_table_direct 1 if the bulk metrics table is read from the driver's file directly, 0 if through the device library.\n"
+            "# TYPE gpumon_engine_metrics_table_direct gauge\n" + table_lines;
   gauge("gpumon_exporter_render_duration_seconds", "Wall time of the previous text render.", (double)last_render_us_ / 1e6);
   gauge("gpumon_exporter_sweeps_total", "File sweeps published.", (double)sweeps_, "counter");
   gauge("gpumon_exporter_scrapes_total", "HTTP scrapes served.", (double)scrapes_, "counter");
@@ -526,11 +536,31 @@ void Exporter::render_self(std::string* out) {
   }
 }
 
+// What a sweep without an output file still has to do: scrapes render on demand, but the last-not-idle latch must
+// see every sample cycle, not only the ones a scraper happens to look at.
+void Exporter::update_latch() {
+  std::lock_guard<std::mutex> l(mu_);
+  const int64_t now_s = now_us() / 1000000;
+  const uint16_t field = GM_FI_GFX_UTIL;
+  for (uint32_t g : gpus_) {
+    gm_value_t v;
+    if (engine_->latest_values(g, &field, 1, &v) != GM_ST_OK || v.status != GM_VS_OK) continue;
+    const int64_t util = v.type == GM_FT_DOUBLE ? (int64_t)v.v.dbl : v.v.i64;
+    auto it = last_not_idle_.find(g);
+    if (it == last_not_idle_.end() || util > 2) {
+      if (it == last_not_idle_.end() || it->second != now_s) state_dirty_ = true;
+      last_not_idle_[g] = now_s;
+    }
+  }
+}
+
 gm_status_t Exporter::publish() {
   if (cfg_.health) check_health();
-  std::string text;
-  render(&text);
-  if (!cfg_.output_path.empty()) {
+  if (cfg_.output_path.empty()) {
+    update_latch();
+  } else {
+    std::string text;
+    render(&text);
     size_t slash = cfg_.output_path.rfind('/');
     if (slash != std::string::npos && slash > 0) mkdir(cfg_.output_path.substr(0, slash).c_str(), 0755);
     if (!write_file_atomic(cfg_.output_path, text.data(), text.size())) {

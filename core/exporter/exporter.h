@@ -87,6 +87,7 @@ class Exporter {
   ~Exporter();
   gm_status_t init();
   void render(std::string* out);  // from the cache; never samples
+  void update_latch();            // the last-not-idle latch alone: what a sweep that writes no file still owes
   gm_status_t publish();          // render + publish file
   gm_status_t sweep();            // force-sample, then publish
   gm_status_t start();

@@ -180,6 +180,15 @@ class RemoteEngine : public Engine {
     *out = r.str();
     return r.ok() ? st : (st != GM_ST_OK ? st : GM_ST_VER_MISMATCH);
   }
+  gm_status_t metrics_table_source(uint32_t gpu, std::string* out) override {
+    WireWriter w;
+    w.u32(gpu);
+    std::string rep;
+    gm_status_t st = call(OP_METRICS_TABLE_SOURCE, w, &rep);
+    WireReader r(rep.data(), rep.size());
+    *out = r.str();
+    return r.ok() ? st : (st != GM_ST_OK ? st : GM_ST_VER_MISMATCH);
+  }
   gm_status_t device_mode(uint32_t gpu, gm_device_mode_t* out) override {
     if (out->version != GM_DEVICE_MODE_VERSION) return GM_ST_VER_MISMATCH;
     WireWriter w;

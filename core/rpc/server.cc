@@ -263,6 +263,13 @@ std::string RpcServer::dispatch(const std::shared_ptr<Client>& c, uint32_t op, c
       w.str(src);
       return w.data();
     }
+    case OP_METRICS_TABLE_SOURCE: {
+      uint32_t gpu = r.u32();
+      std::string src;
+      w.i32(engine_->metrics_table_source(gpu, &src));
+      w.str(src);
+      return w.data();
+    }
     case OP_DEVICE_MODE: {
       uint32_t gpu = r.u32();
       gm_device_mode_t m;

@@ -41,7 +41,7 @@ enum Op : uint32_t {
   OP_WATCH_PID_FIELDS, OP_PID_INFO,
   OP_INTROSPECT_TOGGLE, OP_INTROSPECT,
   OP_EVENT_SUBSCRIBE, OP_EVENT_UNSUBSCRIBE,
-  OP_XGMI_LINKS, OP_HEALTH_THRESHOLDS_SET, OP_HEALTH_THRESHOLDS_GET, OP_DIAG_SUBMIT, OP_DIAG_RESULTS, OP_PROCESS_SOURCE,
+  OP_XGMI_LINKS, OP_HEALTH_THRESHOLDS_SET, OP_HEALTH_THRESHOLDS_GET, OP_DIAG_SUBMIT, OP_DIAG_RESULTS, OP_PROCESS_SOURCE, OP_METRICS_TABLE_SOURCE,
   OP_NOTIFY_VIOLATION = 1000,
   OP_NOTIFY_EVENT = 1001,
 };

@@ -509,6 +509,13 @@ GM_API gm_status_t gm_process_source(uint32_t gpu, char* buf, size_t cap);
  * `render_minor` under `proc_root` ("/proc").  *n: capacity on entry, count on return; `source` as above. */
 GM_API gm_status_t gm_proc_scan(const char* proc_root, const char* pci_bdf, int render_minor, gm_process_t* out, int* n,
                                 char* source, size_t cap);
+/* The amdgpu driver's bulk metrics table (sysfs gpu_metrics) decoded without the device library: `json` gets the
+ * members the sampler uses, all-ones for what the table does not report.  NOT_SUPPORTED (and the reason in `json`)
+ * for a table layout other than format 1 content 8; the engine then keeps to the device library. */
+GM_API gm_status_t gm_metrics_table_decode(const void* raw, size_t n, char* json, size_t cap);
+/* How the amdsmi backend reads that table for this GPU at the moment: "direct" (own read of the sysfs file, checked
+ * against the library) or "library"; with the reason where direct reads were refused. */
+GM_API gm_status_t gm_metrics_table_source(uint32_t gpu, char* buf, size_t cap);
 
 typedef struct {
   uint32_t version;

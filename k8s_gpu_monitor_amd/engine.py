@@ -117,6 +117,27 @@ def process_source(gpu):
     return buf.value.decode()
 
 
+def metrics_table_source(gpu):
+    """How the amdsmi backend reads the bulk metrics table of this GPU: "direct" (its own read of the driver's
+    gpu_metrics file, checked against the library's decoding), "library" or "library: <why direct reads are off>";
+    "n/a" on other backends."""
+    buf = C.create_string_buffer(256)
+    check(lib().gm_metrics_table_source(gpu, buf, C.c_size_t(256)))
+    return buf.value.decode()
+
+
+def metrics_table_decode(raw):
+    """The driver's raw metrics table (bytes of /sys/bus/pci/devices/<bdf>/gpu_metrics) as a dict of the members the
+    sampler uses; all-ones = not reported.  Needs no engine.  ValueError for a layout the decoder does not know."""
+    import json
+    buf = C.create_string_buffer(32768)
+    st = lib().gm_metrics_table_decode(bytes(raw), C.c_size_t(len(raw)), buf, C.c_size_t(32768))
+    if st == A.GM_ST_NOT_SUPPORTED:
+        raise ValueError(buf.value.decode())
+    check(st)
+    return json.loads(buf.value.decode())
+
+
 def proc_scan(proc_root="/proc", pci_bdf="", render_minor=-1):
     """The /proc walk on its own: (source, [process dict]) for the card at pci_bdf / render node render_minor."""
     buf = (A.Process * A.GM_MAX_PROCS)()

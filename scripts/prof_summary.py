@@ -46,10 +46,14 @@ TRAFFIC = [("onepass_kernel<0", 1, 1), ("onepass_kernel<1", 1, 1), ("onepass_ker
            ("onepass_kernel<5", 0, 1), ("read_kernel", 1, 0), ("fill_kernel", 0, 1), ("verify_kernel", 1, 0), ("march_kernel", 1, 1)]
 
 
-def expected_traffic(kernel, buffer_bytes):
+PER_LANE = ("onepass_kernel", "fill_kernel", "march_kernel")  # one 16-byte access per work-item and operand: the grid says how many bytes
+
+
+def expected_traffic(kernel, buffer_bytes, grid):
     for prefix, r, w in TRAFFIC:
         if kernel.startswith(prefix):
-            return r * buffer_bytes, w * buffer_bytes
+            n = 16 * grid if grid and kernel.startswith(PER_LANE) else buffer_bytes
+            return r * n, w * n
     return None
 
 
@@ -80,8 +84,15 @@ def main():
         calls = defaultdict(set)
         regs = {}
         with open(path, newline="") as f:
-            for row in csv.DictReader(f):
+            rows = list(csv.DictReader(f))
+            # one kernel launched over different sizes (a 4 GiB chunk and the 512 MiB scrub buffer): one line per size
+            grids = defaultdict(set)
+            for row in rows:
+                grids[short(row["Kernel_Name"])].add(row.get("Grid_Size", ""))
+            for row in rows:
                 k = short(row["Kernel_Name"])
+                if len(grids[k]) > 1:
+                    k += f" [grid {row.get('Grid_Size', '?')}]"
                 agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
                 calls[k].add(row.get("Dispatch_Id", ""))
                 regs[k] = (row.get("VGPR_Count", "?"), row.get("Accum_VGPR_Count", "?"), row.get("SGPR_Count", "?"),
@@ -100,7 +111,11 @@ def main():
                 lines += [f"With {buffer_bytes / 2**30:.2f} GiB per buffer:", "",
                           "| kernel | bytes read (2 x FETCH_SIZE KiB) | expected | bytes written (WRITE_SIZE KiB) | expected |", "|---|---:|---:|---:|---:|"]
                 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].values())):
-                    exp = expected_traffic(k, buffer_bytes)
+                    try:
+                        grid = int(regs[k][5])
+                    except (KeyError, ValueError):
+                        grid = 0
+                    exp = expected_traffic(k, buffer_bytes, grid)
                     if not exp:
                         continue
                     n = max(1, len(calls[k]))
@@ -112,7 +127,7 @@ def main():
                   "| kernel | VGPR (all) | of which AGPR | SGPR | VGPR spills | LDS bytes (static + at launch) | workgroup | grid | source |",
                   "|---|---:|---:|---:|---:|---:|---:|---:|---|"]
         for k, r in regs.items():
-            co = ours.get(k.split("(")[0])
+            co = ours.get(k.split(" [grid")[0].split("(")[0])
             if co:
                 lines.append(f"| `{k}` | {co['vgpr']} | {co['agpr']} | {co['sgpr']} | {co['spill_vgpr']} | "
                              f"{co['lds_static']} + {co['lds_dynamic']} | {r[4]} | {r[5]} | code object |")

@@ -183,6 +183,27 @@ def test_sampler_honours_frequency_and_retention(engine):
     assert n == 5
 
 
+def test_watches_registered_apart_share_sample_cycles(engine):
+    """Two watches of the same period registered a few tens of milliseconds apart do not wake the sampler twice per
+    period: a slot that comes due within a quarter period joins the cycle that is running, on its nominal schedule."""
+    g = E.group_create("co", [1])
+    first = E.field_group_create("co1", [F["GPU_TEMP"]])
+    second = E.field_group_create("co2", [F["ECC_UE_VOLATILE"]])  # another source, so the cycle is really a shared one
+    E.watch_fields(g, first, update_freq_us=200_000)
+    time.sleep(0.03)
+    E.watch_fields(g, second, update_freq_us=200_000)
+    time.sleep(0.25)  # registration and the first samples are over
+    c0 = E.introspect()["sample_cycles"]
+    time.sleep(2.0)
+    cycles = E.introspect()["sample_cycles"] - c0
+    assert 8 <= cycles <= 12, cycles  # 10 periods: not 20
+    ecc = [t for t, _ in E.values_since(1, F["ECC_UE_VOLATILE"])]
+    temp = [t for t, _ in E.values_since(1, F["GPU_TEMP"])]
+    gaps = [b - a for a, b in zip(ecc, ecc[1:])]
+    assert 150_000 < sum(gaps) / len(gaps) < 250_000, gaps  # the period of the second watch is kept
+    assert len(set(ecc[-5:]) & set(temp)) >= 4  # and its samples carry the first watch's time stamps
+
+
 def test_one_bulk_read_serves_many_fields(engine):
     """Fields of one source ride on the same backend call: watching one metrics
     field makes its siblings visible too (they cost nothing extra)."""

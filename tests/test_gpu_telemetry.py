@@ -280,6 +280,49 @@ def test_volatile_fields_track_amd_smi_within_tolerance(hw):
     assert (before["enc_util"] is None) == (m["usage.mm_activity"] is None)  # blank where the tool says N/A
 
 
+def test_metrics_table_is_read_directly_and_agrees_with_the_library(hw, tmp_path):
+    """The backend reads the driver's bulk metrics table itself (one 16 us read of a kept file descriptor instead of
+    the library's 140 us call), but only after its decoding has matched the library's on this very host.  Here: the
+    switch happened, the raw file decodes to what the engine publishes, and an engine held to the library publishes
+    the same."""
+    import json
+    import subprocess
+    import sys
+    gpu = _engine_index_of_hip0()
+    src = E.metrics_table_source(gpu)
+    if src.startswith("library: table format") or src.startswith("library: table of"):
+        pytest.skip(f"this host's driver produces another table layout ({src})")
+    assert src == "direct", src
+    bdf = E.device_attributes(gpu)["pci_bdf"].lower()
+    with open(f"/sys/bus/pci/devices/{bdf}/gpu_metrics", "rb") as f:
+        raw = E.metrics_table_decode(f.read())
+    g = E.group_create("mt", [gpu])
+    ids = [F["XGMI_BANDWIDTH_TOTAL"], F["MEM_CLOCK"], F["GPU_TEMP"], F["TOTAL_ENERGY"]]
+    fg = E.field_group_create("mt", ids)
+    try:
+        E.watch_fields(g, fg, update_freq_us=100_000)
+        E.update_all_fields(True)
+        v = E.latest_values(gpu, ids)
+    finally:
+        E.unwatch_fields(g, fg)
+        E.group_destroy(g)
+        E.field_group_destroy(fg)
+    links_kb = sum(x for x in raw["xgmi_read_data_acc"] + raw["xgmi_write_data_acc"] if x != 0xFFFFFFFFFFFFFFFF)
+    assert 0 <= v[F["XGMI_BANDWIDTH_TOTAL"]] - links_kb < 1 << 20  # the same accumulators, read a moment later
+    assert v[F["MEM_CLOCK"]] == raw["current_uclk"] and abs(v[F["GPU_TEMP"]] - raw["temperature_hotspot"]) <= 5
+    assert raw["num_partition"] == 1 and raw["pcie_link_width"] == 16
+    # the same reading through the library, in a process of its own
+    code = ("import json; from k8s_gpu_monitor_amd import smi; smi.init(backend='amdsmi'); "
+            f"print(json.dumps(smi.device_status({gpu}))); smi.shutdown()")
+    env = dict(os.environ, GPUMON_METRICS_TABLE="library", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-400:]
+    lib_status = json.loads(r.stdout.strip().splitlines()[-1])
+    here = E.device_status(gpu)
+    assert lib_status["mem_clock_mhz"] == here["mem_clock_mhz"] and abs(lib_status["temperature_c"] - here["temperature_c"]) <= 5
+    assert 0 <= here["energy_mj"] - lib_status["energy_mj"] < 600_000  # same accumulator, read a moment later: under 600 J apart
+
+
 def test_micro_benchmarks(hw):
     """BenchmarkDeviceCount1 / BenchmarkDeviceInfo1 of the reference (nvml_test.go:33-43,118-129;
     dcgm_test.go:33-43,118-129), plus the status read the reference has no benchmark for.  Results are
