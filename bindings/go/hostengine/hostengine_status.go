@@ -34,3 +34,14 @@ func introspect() (Status, error) {
 		Uptime: time.Duration(in.uptime_us) * time.Microsecond, SampleCycles: uint64(in.sample_cycles),
 		BackendErrors: uint64(in.backend_errors), LastCycle: ms(in.last_cycle_ms), AvgCycle: ms(in.avg_cycle_ms)}, nil
 }
+
+// MetricsTableSource tells how the engine's device layer reads the bulk metrics table of a GPU: "direct" (its own
+// read of the driver's gpu_metrics file, checked against the device library's decoding), "library", or
+// "library: <why direct reads are off>"; "n/a" for backends without such a table.
+func MetricsTableSource(gpu uint) (string, error) {
+	var buf [256]C.char
+	if err := check("metrics table source", C.gm_metrics_table_source(C.uint32_t(gpu), &buf[0], C.size_t(len(buf)))); err != nil {
+		return "", err
+	}
+	return C.GoString(&buf[0]), nil
+}
