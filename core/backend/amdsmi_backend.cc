@@ -226,6 +226,15 @@ struct ProfApi {
   decltype(&::gmp_set_count) set_count = nullptr;
 };
 
+// "/sys", or the tree a test has put in its place.
+const std::string& sysfs_root() {
+  static const std::string root = [] {
+    const char* e = getenv("GPUMON_SYSFS_ROOT");
+    return std::string(e && *e ? e : "/sys");
+  }();
+  return root;
+}
+
 std::string sysfs_trim(const std::string& path) {
   std::string s;
   return read_file(path, &s) ? trim(s) : std::string();
@@ -244,7 +253,7 @@ int pcie_gen_from_speed_dgts(uint32_t tenth_gts) {  // 0.1 GT/s units
 // How two PCIe functions relate, from their sysfs device paths.
 gm_link_type_t classify_pcie(const std::string& bdf_a, const std::string& bdf_b, int numa_a, int numa_b) {
   char pa[PATH_MAX], pb[PATH_MAX];
-  std::string a = "/sys/bus/pci/devices/" + bdf_a, b = "/sys/bus/pci/devices/" + bdf_b;
+  std::string a = sysfs_root() + "/bus/pci/devices/" + bdf_a, b = sysfs_root() + "/bus/pci/devices/" + bdf_b;
   if (!realpath(a.c_str(), pa) || !realpath(b.c_str(), pb))
     return numa_a >= 0 && numa_a == numa_b ? GM_LINK_SAME_CPU : GM_LINK_CROSS_CPU;
   std::vector<std::string> ca = split(pa, '/'), cb = split(pb, '/');
@@ -379,7 +388,7 @@ class AmdSmiBackend : public Backend {
     // and complains on stderr at every call.  There the kernel's per-file DRM statistics under /proc answer
     // instead (core/backend/procscan.h): every process this one may look into, with memory and engine time where
     // the kernel writes them and as a bare holder of the render node where it does not.
-    static const int kfd_errno = access("/sys/class/kfd/kfd/proc", R_OK | X_OK) == 0 ? 0 : errno;
+    static const int kfd_errno = access((sysfs_root() + "/class/kfd/kfd/proc").c_str(), R_OK | X_OK) == 0 ? 0 : errno;
     if (kfd_errno || !api_.amdsmi_get_gpu_process_list) {
       static const std::string proc_root = getenv("GPUMON_PROC_ROOT") ? getenv("GPUMON_PROC_ROOT") : "/proc";
       ProcScan scan;
@@ -870,10 +879,10 @@ class AmdSmiBackend : public Backend {
     if (!s.pci_bdf.empty()) {
       // Same sysfs sources as the reference (bindings/go/nvml/nvml.go:294-312, bindings/go/dcgm/topology.go:90-96).
       if (s.numa_node < 0) {
-        std::string n = sysfs_trim("/sys/bus/pci/devices/" + s.pci_bdf + "/numa_node");
+        std::string n = sysfs_trim(sysfs_root() + "/bus/pci/devices/" + s.pci_bdf + "/numa_node");
         if (!n.empty() && atoi(n.c_str()) >= 0) s.numa_node = atoi(n.c_str());
       }
-      s.cpu_affinity = sysfs_trim("/sys/bus/pci/devices/" + s.pci_bdf + "/local_cpulist");
+      s.cpu_affinity = sysfs_trim(sysfs_root() + "/bus/pci/devices/" + s.pci_bdf + "/local_cpulist");
     }
     if (api_.amdsmi_get_energy_count) {
       uint64_t acc = 0, ts = 0;
@@ -905,14 +914,15 @@ class AmdSmiBackend : public Backend {
     uint8_t r0[4096], r1[4096];
     for (int attempt = 0; attempt < 8; attempt++) {
       const ssize_t n0 = pread(d.table_fd, r0, sizeof r0, 0);
+      MetricsTable mine, theirs;
+      if (n0 <= 0) { *why = std::string("read: ") + strerror(errno); return 0; }
+      if (!metrics_table_decode(r0, (size_t)n0, &mine, why)) return 0;  // a layout this build does not know
       amdsmi_gpu_metrics_t a;
       memset(&a, 0xff, sizeof a);
       if (api_.amdsmi_get_gpu_metrics_info(d.h, &a) != AMDSMI_STATUS_SUCCESS) { *why = "the library's read failed"; return -1; }
       const ssize_t n1 = pread(d.table_fd, r1, sizeof r1, 0);
-      if (n0 <= 0 || n0 != n1) { *why = "short read"; return 0; }
+      if (n0 != n1) { *why = "short read"; return 0; }
       if (memcmp(r0, r1, (size_t)n0)) continue;  // the firmware refreshed the table in between
-      MetricsTable mine, theirs;
-      if (!metrics_table_decode(r0, (size_t)n0, &mine, why)) return 0;
       from_library(a, &theirs);
       *why = metrics_table_diff(mine, theirs);
       return why->empty() ? 1 : 0;
@@ -925,13 +935,13 @@ class AmdSmiBackend : public Backend {
     const char* mode = getenv("GPUMON_METRICS_TABLE");  // auto (default) | library
     if (mode && !strcmp(mode, "library")) { d.table_note = "switched off by GPUMON_METRICS_TABLE"; return; }
     if (d.st.pci_bdf.empty()) { d.table_note = "no PCI address"; return; }
-    const std::string path = "/sys/bus/pci/devices/" + d.st.pci_bdf + "/gpu_metrics";
+    const std::string path = sysfs_root() + "/bus/pci/devices/" + d.st.pci_bdf + "/gpu_metrics";
     d.table_fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
     if (d.table_fd < 0) { d.table_note = path + ": " + strerror(errno); return; }
     std::string why;
     const int same = compare_with_library(d, &why);
     if (same != 1) {
-      d.table_note = same ? "not checked: " + why : "differs from the library: " + why;
+      d.table_note = same ? "not checked: " + why : why.rfind("table ", 0) == 0 || why.rfind("read", 0) == 0 ? why : "differs from the library: " + why;
       close(d.table_fd);
       d.table_fd = -1;
       GM_LOGI("amdsmi: gpu %u metrics table through the library (%s)", d.st.index, d.table_note.c_str());
@@ -1339,7 +1349,7 @@ class AmdSmiBackend : public Backend {
     // it is what the library returns where the kernel's mem_info_vram_used counter is
     // not exposed (seen on virtualised hosts).  Report "not supported", not "0 MiB used".
     if (rc == AMDSMI_STATUS_SUCCESS && used == 0 &&
-        access(("/sys/bus/pci/devices/" + d.st.pci_bdf + "/mem_info_vram_used").c_str(), R_OK) != 0)
+        access((sysfs_root() + "/bus/pci/devices/" + d.st.pci_bdf + "/mem_info_vram_used").c_str(), R_OK) != 0)
       rc = AMDSMI_STATUS_NOT_SUPPORTED;
     if (rc == AMDSMI_STATUS_SUCCESS) {
       int64_t used_mib = (int64_t)(used >> 20);

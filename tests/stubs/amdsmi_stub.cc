@@ -1,0 +1,168 @@
+// A stand-in for libamd_smi.so, so that the real device backend (core/backend/amdsmi_backend.cc) runs in the CPU
+// tests: enumeration, the bulk metrics table through the "library" and through the backend's own read of the
+// driver's file, and what happens when the two disagree.  Only the entry points the backend requires are here
+// (plus the ASIC info); every optional one is absent, which the backend must take as "not supported".
+//
+//   STUB_GPUS        number of GPUs, one per socket (default 2); GPU i sits at 0000:<10+i>:00.0
+//   STUB_SYSFS       tree that holds bus/pci/devices/<bdf>/gpu_metrics (format 1 content 8), which this "library"
+//                    translates the way the real one does
+//   STUB_SKEW        added to the hotspot temperature the library reports (a decoding that differs from the file)
+//   STUB_CALLS_FILE  one byte appended per amdsmi_get_gpu_metrics_info call
+// build: g++ -shared -fPIC -O1 -I/opt/rocm/include tests/stubs/amdsmi_stub.cc -o libamd_smi_stub.so
+#include <amd_smi/amdsmi.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace {
+
+struct Gpu { int index; } g_gpus[16];
+struct Socket { int index; } g_sockets[16];
+int g_n = 0;
+
+int env_int(const char* k, int d) {
+  const char* v = getenv(k);
+  return v && *v ? atoi(v) : d;
+}
+template <typename T>
+T rd(const unsigned char* raw, size_t off) {
+  T v;
+  memcpy(&v, raw + off, sizeof v);
+  return v;
+}
+std::string bdf_of(int i) {
+  char b[32];
+  snprintf(b, sizeof b, "0000:%02x:00.0", 0x10 + i);
+  return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+amdsmi_status_t amdsmi_init(uint64_t) {
+  g_n = env_int("STUB_GPUS", 2);
+  if (g_n < 0 || g_n > 16) g_n = 2;
+  for (int i = 0; i < g_n; i++) g_gpus[i].index = g_sockets[i].index = i;
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_shut_down(void) { return AMDSMI_STATUS_SUCCESS; }
+
+amdsmi_status_t amdsmi_get_socket_handles(uint32_t* n, amdsmi_socket_handle* h) {
+  if (!n) return AMDSMI_STATUS_INVAL;
+  if (h)
+    for (int i = 0; i < g_n && i < (int)*n; i++) h[i] = &g_sockets[i];
+  *n = (uint32_t)g_n;
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_processor_handles(amdsmi_socket_handle s, uint32_t* n, amdsmi_processor_handle* h) {
+  if (!n || !s) return AMDSMI_STATUS_INVAL;
+  if (h && *n >= 1) h[0] = &g_gpus[static_cast<Socket*>(s)->index];
+  *n = 1;
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_processor_type(amdsmi_processor_handle, processor_type_t* t) {
+  *t = AMDSMI_PROCESSOR_TYPE_AMD_GPU;
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_device_bdf(amdsmi_processor_handle h, amdsmi_bdf_t* bdf) {
+  bdf->as_uint = 0;
+  bdf->bus_number = 0x10 + static_cast<Gpu*>(h)->index;
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_device_uuid(amdsmi_processor_handle h, unsigned int* len, char* uuid) {
+  snprintf(uuid, *len, "stub-%04d-0000-1000-8000-00000000%04d", static_cast<Gpu*>(h)->index, static_cast<Gpu*>(h)->index);
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_asic_info(amdsmi_processor_handle, amdsmi_asic_info_t* a) {
+  memset(a, 0, sizeof *a);
+  snprintf(a->market_name, sizeof a->market_name, "AMD Instinct MI355X");
+  a->device_id = 0x75a3;
+  a->num_of_compute_units = 256;
+  a->target_graphics_version = 0x950;
+  return AMDSMI_STATUS_SUCCESS;
+}
+
+// The translation of the 1.8 table into the all-versions struct, member by member, as the real library does it.
+amdsmi_status_t amdsmi_get_gpu_metrics_info(amdsmi_processor_handle h, amdsmi_gpu_metrics_t* m) {
+  if (const char* calls = getenv("STUB_CALLS_FILE")) {
+    if (FILE* f = fopen(calls, "ab")) { fputc('.', f); fclose(f); }
+  }
+  const char* root = getenv("STUB_SYSFS");
+  if (!root) return AMDSMI_STATUS_FILE_NOT_FOUND;
+  const std::string path = std::string(root) + "/bus/pci/devices/" + bdf_of(static_cast<Gpu*>(h)->index) + "/gpu_metrics";
+  unsigned char raw[4096];
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return AMDSMI_STATUS_FILE_NOT_FOUND;
+  const size_t n = fread(raw, 1, sizeof raw, f);
+  fclose(f);
+  if (n < 3872 || raw[2] != 1 || raw[3] != 8) return AMDSMI_STATUS_NOT_SUPPORTED;
+  memset(m, 0xff, sizeof *m);
+  m->common_header.structure_size = rd<uint16_t>(raw, 0);
+  m->common_header.format_revision = raw[2];
+  m->common_header.content_revision = raw[3];
+  m->temperature_hotspot = (uint16_t)(rd<uint16_t>(raw, 4) + env_int("STUB_SKEW", 0));
+  m->temperature_mem = rd<uint16_t>(raw, 6);
+  m->temperature_vrsoc = rd<uint16_t>(raw, 8);
+  m->current_socket_power = rd<uint16_t>(raw, 10);
+  m->average_gfx_activity = rd<uint16_t>(raw, 12);
+  m->average_umc_activity = rd<uint16_t>(raw, 14);
+  m->vram_max_bandwidth = rd<uint64_t>(raw, 16);
+  m->energy_accumulator = rd<uint64_t>(raw, 24);
+  m->system_clock_counter = rd<uint64_t>(raw, 32);
+  m->accumulation_counter = rd<uint32_t>(raw, 40);
+  m->prochot_residency_acc = rd<uint32_t>(raw, 44);
+  m->ppt_residency_acc = rd<uint32_t>(raw, 48);
+  m->socket_thm_residency_acc = rd<uint32_t>(raw, 52);
+  m->vr_thm_residency_acc = rd<uint32_t>(raw, 56);
+  m->hbm_thm_residency_acc = rd<uint32_t>(raw, 60);
+  m->gfxclk_lock_status = rd<uint32_t>(raw, 64);
+  m->pcie_link_width = rd<uint16_t>(raw, 68);
+  m->pcie_link_speed = rd<uint16_t>(raw, 70);
+  m->xgmi_link_width = rd<uint16_t>(raw, 72);
+  m->xgmi_link_speed = rd<uint16_t>(raw, 74);
+  m->gfx_activity_acc = rd<uint32_t>(raw, 76);
+  m->mem_activity_acc = rd<uint32_t>(raw, 80);
+  m->pcie_bandwidth_acc = rd<uint64_t>(raw, 88);
+  m->pcie_bandwidth_inst = rd<uint64_t>(raw, 96);
+  m->pcie_l0_to_recov_count_acc = rd<uint64_t>(raw, 104);
+  m->pcie_replay_count_acc = rd<uint64_t>(raw, 112);
+  m->pcie_replay_rover_count_acc = rd<uint64_t>(raw, 120);
+  m->pcie_nak_sent_count_acc = rd<uint32_t>(raw, 128);
+  m->pcie_nak_rcvd_count_acc = rd<uint32_t>(raw, 132);
+  for (int i = 0; i < 8; i++) {
+    m->xgmi_read_data_acc[i] = rd<uint64_t>(raw, 136 + 8 * i);
+    m->xgmi_write_data_acc[i] = rd<uint64_t>(raw, 200 + 8 * i);
+    m->xgmi_link_status[i] = rd<uint16_t>(raw, 264 + 2 * i);
+    m->current_gfxclks[i] = rd<uint16_t>(raw, 296 + 2 * i);
+  }
+  m->firmware_timestamp = rd<uint64_t>(raw, 288);
+  for (int i = 0; i < 4; i++) {
+    m->current_socclks[i] = rd<uint16_t>(raw, 312 + 2 * i);
+    m->current_vclk0s[i] = rd<uint16_t>(raw, 320 + 2 * i);
+    m->current_dclk0s[i] = rd<uint16_t>(raw, 328 + 2 * i);
+  }
+  m->current_uclk = rd<uint16_t>(raw, 336);
+  m->current_gfxclk = m->current_gfxclks[0];
+  m->current_socclk = m->current_socclks[0];
+  m->current_vclk0 = m->current_vclk0s[0];
+  m->current_dclk0 = m->current_dclk0s[0];
+  m->num_partition = rd<uint16_t>(raw, 338);
+  for (int p = 0; p < 8; p++) {
+    const size_t base = 344 + 440 * (size_t)p;
+    for (int x = 0; x < 8; x++) {
+      m->xcp_stats[p].gfx_busy_inst[x] = rd<uint32_t>(raw, base + 4 * x);
+      m->xcp_stats[p].gfx_busy_acc[x] = rd<uint64_t>(raw, base + 120 + 8 * x);
+      m->xcp_stats[p].gfx_below_host_limit_ppt_acc[x] = rd<uint64_t>(raw, base + 184 + 8 * x);
+      m->xcp_stats[p].gfx_below_host_limit_thm_acc[x] = rd<uint64_t>(raw, base + 248 + 8 * x);
+      m->xcp_stats[p].gfx_low_utilization_acc[x] = rd<uint64_t>(raw, base + 312 + 8 * x);
+      m->xcp_stats[p].gfx_below_host_limit_total_acc[x] = rd<uint64_t>(raw, base + 376 + 8 * x);
+    }
+  }
+  m->pcie_lc_perf_other_end_recovery = rd<uint32_t>(raw, 3864);
+  return AMDSMI_STATUS_SUCCESS;
+}
+
+}  // extern "C"

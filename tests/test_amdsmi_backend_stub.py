@@ -1,0 +1,118 @@
+"""The real device backend (core/backend/amdsmi_backend.cc) on the CPU, against a stand-in for libamd_smi.so
+(tests/stubs/amdsmi_stub.cc) and a sysfs tree that holds metrics tables captured from an MI355X.
+
+Covers what otherwise only runs on hardware: enumeration in PCI order, absent optional entry points, the bulk
+metrics table read from the driver's file after it matched the library's decoding, and the fall back to the library
+when it does not match, when the layout is another one, or when the operator says so."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = "/opt/rocm/include/amd_smi/amdsmi.h"
+FIXTURE = os.path.join(ROOT, "tests", "data", "gpu_metrics_v1_8.json")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HEADER) or not shutil.which("g++"), reason="needs the amd_smi header and g++")
+
+PROBE = r"""
+import json, sys
+from k8s_gpu_monitor_amd import abi as A, engine as E
+E.init(backend="amdsmi")
+F = A.FI
+ids = [F["GPU_TEMP"], F["POWER_USAGE"], F["GFX_CLOCK"], F["MEM_CLOCK"], F["GFX_UTIL"], F["XGMI_BANDWIDTH_TOTAL"], F["ENC_UTIL"]]
+out = {"count": E.device_count(), "gpus": []}
+g = E.group_create("all", list(range(E.device_count())))
+fg = E.field_group_create("f", ids)
+E.watch_fields(g, fg, update_freq_us=1_000_000)
+for _ in range(int(sys.argv[1])):
+    E.update_all_fields(True)
+for i in range(E.device_count()):
+    a = E.device_attributes(i)
+    v = E.latest_values(i, ids)
+    out["gpus"].append({"bdf": a["pci_bdf"], "uuid": a["uuid"], "name": a["name"], "num_xcd": a["num_xcd"], "table": E.metrics_table_source(i),
+                        "temp": v[F["GPU_TEMP"]], "power": v[F["POWER_USAGE"]], "gfx_clock": v[F["GFX_CLOCK"]], "mem_clock": v[F["MEM_CLOCK"]],
+                        "util": v[F["GFX_UTIL"]], "xgmi_kb": v[F["XGMI_BANDWIDTH_TOTAL"]], "enc": v[F["ENC_UTIL"]],
+                        "procs": E.process_source(i)})
+E.shutdown()
+print(json.dumps(out))
+"""
+
+
+@pytest.fixture(scope="module")
+def stub(tmp_path_factory):
+    d = tmp_path_factory.mktemp("amdsmi_stub")
+    lib = d / "libamd_smi_stub.so"
+    subprocess.run(["g++", "-shared", "-fPIC", "-O1", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "stubs", "amdsmi_stub.cc"),
+                    "-o", str(lib)], check=True, timeout=120)
+    return lib
+
+
+@pytest.fixture()
+def tables():
+    with open(FIXTURE) as f:
+        return [bytes.fromhex(p["raw"]) for p in json.load(f)["pairs"]]
+
+
+def run_backend(stub, tmp_path, raws, samples=3, **env):
+    sysfs = tmp_path / "sys"
+    for i, raw in enumerate(raws):
+        dev = sysfs / "bus" / "pci" / "devices" / f"0000:{0x10 + i:02x}:00.0"
+        dev.mkdir(parents=True, exist_ok=True)
+        (dev / "gpu_metrics").write_bytes(raw)
+        (dev / "numa_node").write_text("0\n")
+    calls = tmp_path / "calls"
+    e = dict(os.environ, PYTHONPATH=ROOT, GPUMON_AMDSMI_LIB=str(stub), GPUMON_SYSFS_ROOT=str(sysfs), STUB_SYSFS=str(sysfs),
+             STUB_GPUS=str(len(raws)), STUB_CALLS_FILE=str(calls), GPUMON_PROC_ROOT=str(tmp_path / "noproc"), GPUMON_LOG_LEVEL="info")
+    e.pop("GPUMON_BACKEND", None)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, "-c", PROBE, str(samples)], capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode == 0, r.stderr[-800:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out["library_calls"] = calls.stat().st_size if calls.exists() else 0
+    out["stderr"] = r.stderr
+    return out
+
+
+def test_enumeration_and_direct_table(stub, tmp_path, tables):
+    idle, _, load = tables
+    out = run_backend(stub, tmp_path, [idle, load], samples=5)
+    assert out["count"] == 2
+    a, b = out["gpus"]
+    assert (a["bdf"], b["bdf"]) == ("0000:10:00.0", "0000:11:00.0") and a["uuid"] != b["uuid"]
+    assert a["name"] == "AMD Instinct MI355X" and a["num_xcd"] == 8
+    assert a["table"] == b["table"] == "direct"
+    # GPU 0 holds the idle table, GPU 1 the one taken under a GEMM soak
+    assert a["power"] < 400 and a["util"] == 0 and a["gfx_clock"] < 200
+    assert b["power"] >= 1300 and b["util"] == 100 and 1500 < b["gfx_clock"] < 2400 and b["mem_clock"] == 2000
+    assert 40 <= a["temp"] <= b["temp"] <= 110
+    assert a["enc"] is None  # no encoder on this part: blank, not zero
+    assert a["xgmi_kb"] > 0
+    # the library was asked for the table while enumerating and checking, never for a sample:
+    # two reads per GPU at start (XCD count, comparison), none for the five sample cycles
+    assert out["library_calls"] <= 2 * 2 + 2, out["library_calls"]
+    assert a["procs"] == "none"  # no KFD table, no /proc tree: says so instead of an empty list that looks like "idle"
+
+
+def test_a_library_that_decodes_differently_wins(stub, tmp_path, tables):
+    out = run_backend(stub, tmp_path, [tables[2]], samples=4, STUB_SKEW=3)
+    g = out["gpus"][0]
+    assert g["table"].startswith("library: differs from the library: temperature_hotspot"), g["table"]
+    # the values are the library's (skewed by 3), and every sample went through it
+    direct = run_backend(stub, tmp_path, [tables[2]], samples=4)["gpus"][0]
+    assert direct["table"] == "direct" and g["temp"] == direct["temp"] + 3
+    assert out["library_calls"] >= 4 + 2
+
+
+def test_other_layout_or_operator_choice_keeps_the_library(stub, tmp_path, tables):
+    out = run_backend(stub, tmp_path, [tables[0]], GPUMON_METRICS_TABLE="library")
+    assert out["gpus"][0]["table"] == "library: switched off by GPUMON_METRICS_TABLE" and out["gpus"][0]["temp"] > 0
+    # a table of another revision: the stub library refuses it as well, so values are blank, and the reason is kept
+    v17 = bytearray(tables[0])
+    v17[3] = 7
+    out = run_backend(stub, tmp_path, [bytes(v17)])
+    assert out["gpus"][0]["table"] == "library: table format 1.7 (this decoder reads 1.8)", out["gpus"][0]["table"]
+    assert out["gpus"][0]["temp"] is None
