@@ -484,11 +484,15 @@ def run(a, world, dev, exporter, torch, dist, K, sz, busbw_factor):
             "exporter_prof_counters": bool(a.prof_counters),
         })
         try:
-            m = re.search(rb'^dcgm_fi_prof_pipe_tensor_active\{gpu="0"[^}]*\} (\S+)', exporter.scrape()[1], re.M)
+            last = exporter.scrape()[1]
         except SCRAPE_ERRORS:
-            m = None
+            last = b""
+        m = re.search(rb'^dcgm_fi_prof_pipe_tensor_active\{gpu="0"[^}]*\} (\S+)', last, re.M)
         if m:
             extras["tensor_active_percent_gpu0_last_scrape"] = float(m.group(1))
+        direct = re.findall(rb'^gpumon_engine_metrics_table_direct\{[^}]*\} (\d)', last, re.M)
+        if direct:  # how the exporter reads the bulk metrics table: the driver's file itself, or through the device library
+            extras["exporter_metrics_table_direct_gpus"] = sum(int(x) for x in direct)
     if scrape_failures:
         extras["scrape_error"] = scrape_failures[0]
         extras["exporter_exit_code"] = exporter.proc.poll()
