@@ -506,11 +506,19 @@ void Exporter::render_self(std::string* out) {
     gauge("gpumon_engine_backend_errors_total", "Device-library calls that failed.", (double)in.backend_errors, "counter");
   }
   // Where each GPU's process list comes from on this host; "open-files" means per-process memory is unknown.
-  std::string src_lines;
-  for (uint32_t g : gpus_) {
-    std::string src;
-    if (engine_->process_source(g, &src) == GM_ST_OK) src_lines += strprintf("gpumon_engine_process_source{gpu=\"%u\",source=\"%s\"} 1\n", g, src.c_str());
+  // Asking costs a look at the process list (a walk over /proc where the driver's table is closed): once a minute,
+  // not once a scrape.
+  const int64_t now_mono = monotonic_us();
+  if (proc_source_.size() != gpus_.size() || now_mono - proc_source_mono_ > 60 * 1000000ll) {
+    proc_source_.assign(gpus_.size(), "");
+    for (size_t i = 0; i < gpus_.size(); i++)
+      if (engine_->process_source(gpus_[i], &proc_source_[i]) != GM_ST_OK) proc_source_[i].clear();
+    proc_source_mono_ = now_mono;
   }
+  std::string src_lines;
+  for (size_t i = 0; i < gpus_.size(); i++)
+    if (!proc_source_[i].empty())
+      src_lines += strprintf("gpumon_engine_process_source{gpu=\"%u\",source=\"%s\"} 1\n", gpus_[i], proc_source_[i].c_str());
   if (!src_lines.empty())
     *out += "# HELP gpumon_engine_process_source Source of the per-GPU process list: kfd, fdinfo, open-files, fake or none.\n"
             "# TYPE gpumon_engine_process_source gauge\n" + src_lines;

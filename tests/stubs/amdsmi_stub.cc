@@ -8,6 +8,10 @@
 //                    translates the way the real one does
 //   STUB_SKEW        added to the hotspot temperature the library reports (a decoding that differs from the file)
 //   STUB_CALLS_FILE  one byte appended per amdsmi_get_gpu_metrics_info call
+//   STUB_SCRIPT      file of key=value lines read at every call of the optional entry points, so that a test can
+//                    change the device under a running engine: ecc_ce ecc_ue ecc_deferred (totals), ecc_status
+//                    (a library status code for the RAS calls: 0 ok, 10 = no permission, 2 = not supported),
+//                    vram_used_mib, bad_reserved, bad_pending, perf_level, power_cap_w
 // build: g++ -shared -fPIC -O1 -I/opt/rocm/include tests/stubs/amdsmi_stub.cc -o libamd_smi_stub.so
 #include <amd_smi/amdsmi.h>
 
@@ -82,6 +86,71 @@ amdsmi_status_t amdsmi_get_gpu_asic_info(amdsmi_processor_handle, amdsmi_asic_in
   a->device_id = 0x75a3;
   a->num_of_compute_units = 256;
   a->target_graphics_version = 0x950;
+  return AMDSMI_STATUS_SUCCESS;
+}
+
+// ---- optional entry points, scripted --------------------------------------------------------------------------
+static long script(const char* key, long dflt) {
+  const char* path = getenv("STUB_SCRIPT");
+  if (!path) return dflt;
+  FILE* f = fopen(path, "r");
+  if (!f) return dflt;
+  char line[256];
+  long v = dflt;
+  const size_t kl = strlen(key);
+  while (fgets(line, sizeof line, f))
+    if (!strncmp(line, key, kl) && line[kl] == '=') v = atol(line + kl + 1);
+  fclose(f);
+  return v;
+}
+
+amdsmi_status_t amdsmi_get_gpu_memory_total(amdsmi_processor_handle, amdsmi_memory_type_t t, uint64_t* total) {
+  *total = t == AMDSMI_MEM_TYPE_VRAM ? 294896ull << 20 : 1ull << 30;
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_memory_usage(amdsmi_processor_handle, amdsmi_memory_type_t t, uint64_t* used) {
+  if (t != AMDSMI_MEM_TYPE_VRAM) return AMDSMI_STATUS_NOT_SUPPORTED;
+  *used = (uint64_t)script("vram_used_mib", 0) << 20;  // 0: what the real library says where the kernel counter is missing
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_total_ecc_count(amdsmi_processor_handle, amdsmi_error_count_t* ec) {
+  const long st = script("ecc_status", 0);
+  if (st) return (amdsmi_status_t)st;
+  memset(ec, 0, sizeof *ec);
+  ec->correctable_count = (uint64_t)script("ecc_ce", 0);
+  ec->uncorrectable_count = (uint64_t)script("ecc_ue", 0);
+  ec->deferred_count = (uint64_t)script("ecc_deferred", 0);
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_ecc_count(amdsmi_processor_handle, amdsmi_gpu_block_t block, amdsmi_error_count_t* ec) {
+  const long st = script("ecc_status", 0);
+  if (st) return (amdsmi_status_t)st;
+  memset(ec, 0, sizeof *ec);
+  if (block == AMDSMI_GPU_BLOCK_UMC) {  // all errors of the script are memory errors
+    ec->correctable_count = (uint64_t)script("ecc_ce", 0);
+    ec->uncorrectable_count = (uint64_t)script("ecc_ue", 0);
+  }
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_bad_page_info(amdsmi_processor_handle, uint32_t* n, amdsmi_retired_page_record_t* recs) {
+  const uint32_t reserved = (uint32_t)script("bad_reserved", 0), pending = (uint32_t)script("bad_pending", 0);
+  if (recs)
+    for (uint32_t i = 0; i < reserved + pending && i < *n; i++) {
+      recs[i].page_address = 0x1000ull * (i + 1);
+      recs[i].page_size = 4096;
+      recs[i].status = i < reserved ? AMDSMI_MEM_PAGE_STATUS_RESERVED : AMDSMI_MEM_PAGE_STATUS_PENDING;
+    }
+  *n = reserved + pending;
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_perf_level(amdsmi_processor_handle, amdsmi_dev_perf_level_t* lvl) {
+  *lvl = (amdsmi_dev_perf_level_t)script("perf_level", (long)AMDSMI_DEV_PERF_LEVEL_AUTO);
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_power_cap_info(amdsmi_processor_handle, uint32_t, amdsmi_power_cap_info_t* p) {
+  memset(p, 0, sizeof *p);
+  p->power_cap = (uint64_t)script("power_cap_w", 1400) * 1000000ull;
+  p->max_power_cap = 1400ull * 1000000ull;
   return AMDSMI_STATUS_SUCCESS;
 }
 

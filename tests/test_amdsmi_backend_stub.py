@@ -116,3 +116,74 @@ def test_other_layout_or_operator_choice_keeps_the_library(stub, tmp_path, table
     out = run_backend(stub, tmp_path, [bytes(v17)])
     assert out["gpus"][0]["table"] == "library: table format 1.7 (this decoder reads 1.8)", out["gpus"][0]["table"]
     assert out["gpus"][0]["temp"] is None
+
+
+PROBE_OPTIONAL = r"""
+import json, os, sys, time
+from k8s_gpu_monitor_amd import abi as A, engine as E
+script = os.environ["STUB_SCRIPT"]
+def device(**kv):
+    with open(script + ".tmp", "w") as f:
+        f.write("".join(f"{k}={v}\n" for k, v in kv.items()))
+    os.replace(script + ".tmp", script)
+device(ecc_ce=5, ecc_ue=0, vram_used_mib=2048, bad_reserved=2, bad_pending=1, power_cap_w=1200)
+E.init(backend="amdsmi")
+F = A.FI
+ids = [F["ECC_CE_VOLATILE"], F["ECC_UE_VOLATILE"], F["ECC_UMC_UE"], F["VRAM_USED"], F["VRAM_FREE"], F["VRAM_TOTAL"], F["BAD_PAGES_UE"],
+       F["BAD_PAGES_PENDING"], F["BAD_PAGES_CE"], F["XGMI_ERROR_STATUS"], F["LAST_EVENT_CODE"]]
+g = E.group_create("g", [0]); fg = E.field_group_create("f", ids)
+E.watch_fields(g, fg, update_freq_us=1_000_000)
+out = {}
+def snap(name):
+    E.update_all_fields(True)
+    raw = E.latest_values(0, ids, raw=True)
+    out[name] = {k: (raw[i].py(), raw[i].status) for i, k in enumerate(["ce", "ue", "umc_ue", "vram_used", "vram_free", "vram_total", "bad_ue",
+                                                                           "bad_pending", "bad_ce", "xgmi_err", "event"])}
+snap("first")
+E.health_set(g)
+E.health_check(g)  # the baseline the next check compares with
+device(ecc_ce=5, ecc_ue=2, vram_used_mib=4096, bad_reserved=3, bad_pending=0, power_cap_w=1200)
+snap("after_ue")
+time.sleep(0.2)  # the event reaches the field through the notifier thread
+snap("after_event")
+h = E.health_check(g)[0]
+out["health"] = {"status": h["status"], "overall": h["overall"], "incidents": h.get("incidents")}
+device(ecc_status=10)
+snap("no_perm")
+device(ecc_ce=5, ecc_ue=2, vram_used_mib=0)
+snap("vram_zero")
+E.shutdown()
+print(json.dumps(out, default=str))
+"""
+
+
+def test_optional_sources_and_the_ras_chain_through_the_real_backend(stub, tmp_path, tables):
+    sysfs = tmp_path / "sys"
+    dev = sysfs / "bus" / "pci" / "devices" / "0000:10:00.0"
+    dev.mkdir(parents=True)
+    (dev / "gpu_metrics").write_bytes(tables[0])
+    (dev / "mem_info_vram_used").write_text("0\n")
+    from k8s_gpu_monitor_amd import abi as A
+    e = dict(os.environ, PYTHONPATH=ROOT, GPUMON_AMDSMI_LIB=str(stub), GPUMON_SYSFS_ROOT=str(sysfs), STUB_SYSFS=str(sysfs), STUB_GPUS="1",
+             STUB_SCRIPT=str(tmp_path / "script"), GPUMON_PROC_ROOT=str(tmp_path / "noproc"))
+    e.pop("GPUMON_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", PROBE_OPTIONAL], capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode == 0, r.stderr[-800:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    first, after = out["first"], out["after_event"]
+    assert first["ce"][0] == 5 and first["ue"][0] == 0 and first["umc_ue"][0] == 0
+    assert first["vram_used"][0] == 2048 and first["vram_total"][0] == 294896 and first["vram_free"][0] == 294896 - 2048
+    assert first["bad_ue"][0] == 2 and first["bad_pending"][0] == 1
+    assert first["bad_ce"] == [None, A.GM_VS_NOT_SUPPORTED]      # the driver does not say why a page was retired
+    assert first["xgmi_err"] == [None, A.GM_VS_NOT_SUPPORTED]    # entry point absent from the library
+    assert first["event"][0] in (None, 0)
+    # two uncorrectable errors between two samples: the counters move, and the step becomes a RAS event
+    assert out["after_ue"]["ue"][0] == 2 and out["after_ue"]["umc_ue"][0] == 2 and out["after_ue"]["bad_ue"][0] == 3
+    assert after["event"][0] == A.EVENT["RAS_UE"], after
+    assert out["health"]["overall"] == 20, out["health"]  # uncorrectable memory errors and a growing bad-page table: failure
+    # the library refusing the RAS calls blanks those fields with the reason, and nothing else
+    np_ = out["no_perm"]
+    assert np_["ue"] == [None, A.GM_VS_NO_PERMISSION] and np_["umc_ue"] == [None, A.GM_VS_NO_PERMISSION]
+    assert np_["vram_total"][0] == 294896
+    # 0 bytes used with the kernel counter present is a reading (the file exists in this tree)
+    assert out["vram_zero"]["vram_used"][0] == 0
