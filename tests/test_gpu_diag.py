@@ -463,6 +463,37 @@ def test_link_test_kernels_and_the_one_gpu_case(diag):
     assert st["destinations"] == 7 and st["bad_words"] == 0 and 0 < st["window_ms_min"] <= st["window_ms_max"] <= st["launch_ms"] * 1.02 + 0.05
 
 
+def test_whole_link_test_rehearsed_with_one_card_in_four_positions():
+    """Every pattern of the link test, both directions, the per-position buffers and the data checks, the grading and
+    the report, with one card standing in four positions (its own memory plays the peers'): what a node with four GPUs
+    runs, minus the links.  The rates are local-memory rates and so pass any link expectation; what is checked is
+    that every cell of every matrix is measured and verified, and that a seeded slow expectation is read into findings
+    that name position and peer."""
+    rc, doc = _run_diag("links", "--gpus", "0,0,0,0", "--bytes", "64M", "--iters", "3", "--direction", "both",
+                        env={"GPUMON_DIAG_ALLOW_REPEAT": "1"}, timeout=170)
+    assert rc == 0 and doc["result"] == "pass", doc["verdicts"]
+    links = doc["links"]
+    assert links["gpus"] == 4 and links["findings"] == []
+    for direction in ("push", "pull"):
+        for pattern in ("uni", "bidi", "all"):
+            g = links[direction][pattern]
+            assert len(g) == 4 and all(len(row) == 4 for row in g)
+            for i in range(4):
+                for j in range(4):
+                    assert (g[i][j] == 0) if i == j else (g[i][j] > 50), (direction, pattern, i, j, g[i][j])
+        assert len(links[direction]["per_gpu_gbps"]) == 4 and min(links[direction]["per_gpu_gbps"]) > 150
+        assert links[direction]["expected_gbps"]["uni"] > links[direction]["expected_gbps"]["all"] > 0
+    assert doc["verdicts"] and all(v["test"] == "xgmi_p2p" and v["health"] == 0 for v in doc["verdicts"])
+    # held against a link that could never be this slow, nothing changes; against one a hundred times faster than local
+    # memory, every pair is a finding
+    rc, slow = _run_diag("links", "--gpus", "0,0,0", "--bytes", "32M", "--iters", "2", "--link-gbps", "1000000",
+                         env={"GPUMON_DIAG_ALLOW_REPEAT": "1"}, timeout=170)
+    assert rc == 1 and slow["result"] == "fail"
+    kinds = {f["kind"] for f in slow["links"]["findings"]}
+    assert kinds & {"slow_link", "low_egress", "low_ingress"}, kinds
+    assert all(f["health"] == 20 and f["gpu"] == 0 for f in slow["links"]["findings"])
+
+
 def test_fused_all_peers_launch_and_its_two_clocks(diag):
     """One launch that serves seven destinations at once (what the link test's "all" pattern runs per GPU), with local
     buffers standing in for the peers.  Every destination gets its data and nothing past its end; the per-destination
