@@ -466,14 +466,13 @@ def test_link_test_kernels_and_the_one_gpu_case(diag):
 def test_whole_link_test_rehearsed_with_one_card_in_four_positions():
     """Every pattern of the link test, both directions, the per-position buffers and the data checks, the grading and
     the report, with one card standing in four positions (its own memory plays the peers'): what a node with four GPUs
-    runs, minus the links.  The rates are local-memory rates and so pass any link expectation; what is checked is
-    that every cell of every matrix is measured and verified, and that a seeded slow expectation is read into findings
-    that name position and peer."""
+    runs, minus the links.  One at a time every "link" runs at local-memory rate and passes any link expectation.
+    With both directions or all positions busy the one memory system is shared, which the diagnosis reads, correctly,
+    as links that do not hold their rate under load: those findings are allowed, the others are not."""
     rc, doc = _run_diag("links", "--gpus", "0,0,0,0", "--bytes", "64M", "--iters", "3", "--direction", "both",
                         env={"GPUMON_DIAG_ALLOW_REPEAT": "1"}, timeout=170)
-    assert rc == 0 and doc["result"] == "pass", doc["verdicts"]
     links = doc["links"]
-    assert links["gpus"] == 4 and links["findings"] == []
+    assert links["gpus"] == 4
     for direction in ("push", "pull"):
         for pattern in ("uni", "bidi", "all"):
             g = links[direction][pattern]
@@ -481,17 +480,20 @@ def test_whole_link_test_rehearsed_with_one_card_in_four_positions():
             for i in range(4):
                 for j in range(4):
                     assert (g[i][j] == 0) if i == j else (g[i][j] > 50), (direction, pattern, i, j, g[i][j])
+        assert min(min(x for x in row if x) for row in links[direction]["uni"]) > 500   # one at a time: local memory
         assert len(links[direction]["per_gpu_gbps"]) == 4 and min(links[direction]["per_gpu_gbps"]) > 150
         assert links[direction]["expected_gbps"]["uni"] > links[direction]["expected_gbps"]["all"] > 0
-    assert doc["verdicts"] and all(v["test"] == "xgmi_p2p" and v["health"] == 0 for v in doc["verdicts"])
-    # held against a link that could never be this slow, nothing changes; against one a hundred times faster than local
-    # memory, every pair is a finding
+    kinds = {f["kind"] for f in links["findings"]}
+    assert kinds <= {"half_duplex", "slow_under_load", "low_egress", "low_ingress"}, kinds   # no access, data or single-link finding
+    assert all(f["gpu"] == 0 and f["direction"] in ("push", "pull") and f["pattern"] in ("bidi", "all") for f in links["findings"])
+    assert rc == (1 if any(f["health"] == 20 for f in links["findings"]) else 0)
+    assert doc["verdicts"] and all(v["test"] == "xgmi_p2p" for v in doc["verdicts"])
+    # held against a link a thousand times faster than local memory, every pair is too slow already when it runs alone
     rc, slow = _run_diag("links", "--gpus", "0,0,0", "--bytes", "32M", "--iters", "2", "--link-gbps", "1000000",
                          env={"GPUMON_DIAG_ALLOW_REPEAT": "1"}, timeout=170)
     assert rc == 1 and slow["result"] == "fail"
-    kinds = {f["kind"] for f in slow["links"]["findings"]}
-    assert kinds & {"slow_link", "low_egress", "low_ingress"}, kinds
-    assert all(f["health"] == 20 and f["gpu"] == 0 for f in slow["links"]["findings"])
+    found = [f for f in slow["links"]["findings"] if f["kind"] == "slow_link"]
+    assert len(found) >= 6 and all(f["health"] == 20 and f["pattern"] == "uni" and f["expected_gbps"] > 100000 for f in found), slow["links"]["findings"]
 
 
 def test_fused_all_peers_launch_and_its_two_clocks(diag):
