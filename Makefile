@@ -24,7 +24,7 @@ CORE_SRC := core/common/util.cc core/common/json.cc core/fields.cc \
 CORE_OBJ := $(CORE_SRC:%.cc=$(BUILD)/obj/%.o)
 BINS     := gpumon gpumon-exporter gpumon-hostengine gpumon-pod-exporter
 DIAG_HIP := diag/hip/hbm_stream.hip diag/hip/memtest.hip diag/hip/mfma_gemm.hip diag/hip/diag_api.hip \
-            diag/rccl/rccl_sweep.hip diag/hip/link_test.hip
+            diag/rccl/rccl_sweep.hip diag/hip/link_test.hip diag/hip/pcie_test.hip
 DIAG_OBJ := $(DIAG_HIP:%.hip=$(BUILD)/obj/%.o)
 HIPFLAGS += --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Idiag -Wno-unused-result -Wno-inline-asm
 

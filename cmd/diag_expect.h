@@ -26,6 +26,9 @@ struct Table {
   double memtest_write_tbps, memtest_verify_tbps, memtest_march_tbps;  // march: bytes read plus bytes written
   double mfma_tflops[4];    // bf16 fp8 f32 mxfp8, register-resident pipe peak
   double gemm_tflops[4];    // bf16 fp8 - mxfp8 at 8192^3, sustained, checks on
+  // Host link: share of what the negotiated PCIe link carries in one direction (generation x width), per traffic
+  // pattern: copy engines up, down, each direction with both busy; a kernel reading and writing host memory.
+  double pcie_fraction[5];
   double soak_gfx_clock_mhz;     // average shader clock held under the GEMM soak
   double soak_power_fraction;    // average board power over the power cap: a part that cannot draw its power is held back by something
   // Limits: lower is better; {warn at, fail at}.
@@ -41,6 +44,7 @@ inline const std::vector<Table>& tables() {
        {6.5, 6.5, 6.5, 6.5, 6.8, 7.0}, 6.8, 6.5, 5.8,
        {2200, 2300, 150, 4700},
        {1550, 3000, 0, 3000},
+       {0.88, 0.88, 0.72, 0.82, 0.80},
        1700, 0.80,
        {95, 105}, {85, 95}, {0.01, 0.10}},
   };
@@ -65,6 +69,7 @@ struct Expect {
 
 inline const char* const kStream[] = {"copy", "scale", "add", "triad", "read", "write"};
 inline const char* const kDtype[] = {"bf16", "fp8", "f32", "mxfp8"};
+inline const char* const kPcie[] = {"h2d", "d2h", "bidir", "kernel_read", "kernel_write"};
 
 inline Expect lookup(const std::string& arch, const std::string& name) {
   Expect e;
@@ -80,6 +85,7 @@ inline Expect lookup(const std::string& arch, const std::string& name) {
       e.v[std::string("mfma.") + kDtype[i]] = t.mfma_tflops[i];
       if (t.gemm_tflops[i] > 0) e.v[std::string("gemm.") + kDtype[i]] = t.gemm_tflops[i];
     }
+    for (int i = 0; i < 5; i++) e.v[std::string("pcie.") + kPcie[i]] = t.pcie_fraction[i];
     e.v["soak.gfx_clock_mhz"] = t.soak_gfx_clock_mhz;
     e.v["soak.power_fraction"] = t.soak_power_fraction;
     e.v["limit.hotspot_c.warn"] = t.hotspot_c[0], e.v["limit.hotspot_c.fail"] = t.hotspot_c[1];

@@ -66,7 +66,8 @@ const char* kFlagsWithValue[] = {"-g", "--bytes", "--iters", "--kernel", "--min-
                                  "--dtype", "--seconds", "--m", "--n", "--k", "--gpus", "--ops", "--min-bytes",
                                  "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor", "--publish", "--modes", "--floor-gbps",
                                  "--warn-ratio", "--fail-ratio", "--workgroups", "--submit", "--min-busbw", "--expect", "--expect-scale",
-                                 "--check-every", "--direction", "--link-gbps", "--outlier-warn", "--outlier-fail", "--arch", "--name", "--check"};
+                                 "--check-every", "--direction", "--link-gbps", "--outlier-warn", "--outlier-fail", "--arch", "--name", "--check",
+                                 "--pcie-gen", "--pcie-width"};
 
 bool parse(const std::vector<std::string>& in, Args* a) {
   for (size_t i = 0; i < in.size(); i++) {
@@ -431,6 +432,75 @@ int cmd_hbm(const Args& a, Report& r, int gpu) {
   }
   r.verdict_pass("hbm_stream", GM_HEALTH_WATCH_MEM, worst, e.known ? "every stream kernel verified and at its expected rate" : "every stream kernel verified");
   r.member("hbm_stream", obj + "}");
+  return 0;
+}
+
+// The negotiated PCIe link of a GPU from sysfs ("32.0 GT/s PCIe", "16"); flags override, 0 = unknown.
+void pcie_link_of(const Args& a, int gpu, int* gen, int* width) {
+  *gen = (int)a.num("--pcie-gen", 0), *width = (int)a.num("--pcie-width", 0);
+  const std::string dir = "/sys/bus/pci/devices/" + bdf_of_hip(gpu) + "/";
+  auto first_line = [](const std::string& path) {
+    std::string s;
+    if (FILE* f = fopen(path.c_str(), "r")) {
+      char buf[128];
+      if (fgets(buf, sizeof buf, f)) s = buf;
+      fclose(f);
+    }
+    return s;
+  };
+  if (*gen <= 0) {
+    const double gts = atof(first_line(dir + "current_link_speed").c_str());
+    *gen = gts >= 63 ? 6 : gts >= 31 ? 5 : gts >= 15 ? 4 : gts >= 7.5 ? 3 : gts >= 4.5 ? 2 : gts >= 2 ? 1 : 0;
+  }
+  if (*width <= 0) *width = atoi(first_line(dir + "current_link_width").c_str());
+}
+
+int cmd_pcie(const Args& a, Report& r, int gpu) {
+  diag_expect::Expect e;
+  if (!expect_for(a, gpu, &e)) return 2;
+  gmd_pcie_config_t c;
+  memset(&c, 0, sizeof c);
+  c.bytes = a.size("--bytes", 256ull << 20);
+  c.iters = (int)a.num("--iters", 5);
+  c.verify = a.has("--no-verify") ? 0 : 1;
+  c.workgroups = (int)a.num("--workgroups", 0);
+  gmd_pcie_result_t p;
+  DIAG_CALL(r, gmd_pcie_test(gpu, &c, &p));
+  int gen = 0, width = 0;
+  pcie_link_of(a, gpu, &gen, &width);
+  const double link = gmd_pcie_link_gbps(gen, width);
+  r.text("host link of GPU %d: %s, %.0f MiB per transfer, %d iterations\n", gpu,
+         link > 0 ? strprintf_local("PCIe generation %d x%d, %.1f GB/s per direction", gen, width, link).c_str() : "link generation and width unknown", p.bytes / 1048576.0, p.iters);
+  const struct { const char* key; const char* what; double got; uint64_t bad; } rows[5] = {
+      {"h2d", "copy engine, host to device", p.h2d_gbps, p.bad_h2d},
+      {"d2h", "copy engine, device to host", p.d2h_gbps, p.bad_d2h},
+      {"bidir", "both at once (slower direction)", std::min(p.bidir_h2d_gbps, p.bidir_d2h_gbps), 0},
+      {"kernel_read", "kernel reads host memory", p.kernel_read_gbps, p.bad_kernel_read},
+      {"kernel_write", "kernel writes host memory", p.kernel_write_gbps, p.bad_kernel_write}};
+  std::string obj = "{\"link_gen\":" + std::to_string(gen) + ",\"link_width\":" + std::to_string(width) + ",\"link_gbps\":" + jnum(link) +
+                    ",\"bytes\":" + std::to_string(p.bytes) + ",\"bidir_h2d_gbps\":" + jnum(p.bidir_h2d_gbps) + ",\"bidir_d2h_gbps\":" + jnum(p.bidir_d2h_gbps) +
+                    ",\"small_h2d_us\":" + jnum(p.small_h2d_us) + ",\"small_d2h_us\":" + jnum(p.small_d2h_us);
+  r.text("  %-34s %9s %9s %8s\n", "traffic", "GB/s", "expected", "check");
+  uint64_t bad_total = 0;
+  double worst_share = 1e30;
+  for (auto& row : rows) {
+    const double want = link > 0 ? e.want(std::string("pcie.") + row.key) * link : 0;
+    r.text("  %-34s %9.1f %9s %8s\n", row.what, row.got, want > 0 ? strprintf_local("%.1f", want).c_str() : "-",
+           !p.verified ? "-" : row.bad ? "WRONG" : "ok");
+    obj += std::string(",\"") + row.key + "_gbps\":" + jnum(row.got) + ",\"" + row.key + "_expected_gbps\":" + (want > 0 ? jnum(want) : "null");
+    r.metrics[std::string("pcie.") + row.key] = row.got;
+    bad_total += row.bad;
+    if (row.bad) r.verdict_fail("pcie_link", GM_HEALTH_WATCH_PCIE, (double)row.bad, "%s: %llu corrupt 16-byte words", row.what, (unsigned long long)row.bad);
+    r.grade("pcie_link", GM_HEALTH_WATCH_PCIE, row.what, row.got, want, e, "GB/s");
+    if (link > 0) worst_share = std::min(worst_share, row.got / link);
+  }
+  if (p.bidir_h2d_gbps > 0)
+    r.text("  both at once: %.1f up + %.1f down GB/s; an 8-byte copy takes %.1f us up, %.1f us down\n", p.bidir_h2d_gbps, p.bidir_d2h_gbps, p.small_h2d_us,
+           p.small_d2h_us);
+  obj += ",\"bad_words\":" + std::to_string(bad_total) + "}";
+  r.member("pcie", obj);
+  r.verdict_pass("pcie_link", GM_HEALTH_WATCH_PCIE, link > 0 ? 100 * worst_share : p.h2d_gbps,
+                 link > 0 && e.known ? "every transfer verified and at its expected share of the link" : "every transfer verified");
   return 0;
 }
 
@@ -1182,7 +1252,7 @@ int cmd_links(const Args& a, Report& r) {
 // all GPUs' load together; afterwards every GPU's rates are held against the median of the others.
 using GpuTest = std::function<int(const Args&, Report&, int)>;
 
-int run_on(const Args& a, Report& r, const std::vector<int>& gpus, const GpuTest& fn) {
+int run_on(const Args& a, Report& r, const std::vector<int>& gpus, const GpuTest& fn, bool one_at_a_time = false) {
   if (gpus.size() == 1) {  // one GPU: the report is that GPU's
     r.gpu = gpus[0];
     r.pci_bdf = bdf_of_hip(gpus[0]);
@@ -1199,8 +1269,12 @@ int run_on(const Args& a, Report& r, const std::vector<int>& gpus, const GpuTest
   }
   std::vector<int> rcs(gpus.size(), 0);
   std::vector<std::thread> th;
-  for (size_t i = 0; i < gpus.size(); i++) th.emplace_back([&, i] { rcs[i] = fn(a, r.subs[i], gpus[i]); });
-  for (auto& t : th) t.join();
+  for (size_t i = 0; i < gpus.size(); i++) {
+    th.emplace_back([&, i] { rcs[i] = fn(a, r.subs[i], gpus[i]); });
+    if (one_at_a_time) th.back().join();  // tests of something the GPUs share (the host's memory and root ports)
+  }
+  for (auto& t : th)
+    if (t.joinable()) t.join();
   int rc = 0;
   for (size_t i = 0; i < gpus.size(); i++) {
     if (!r.json && !r.subs[i].out.empty()) {
@@ -1241,6 +1315,7 @@ void compare_gpus(const Args& a, Report& r) {
       r.text(" %9.4g%s", v[i], h[i] >= GM_HEALTH_FAIL ? "!!" : h[i] ? "! " : "  ");
       if (!std::isfinite(v[i])) continue;
       const uint32_t system = key.rfind("hbm.", 0) == 0 || key.rfind("memtest.", 0) == 0 ? GM_HEALTH_WATCH_MEM
+                              : key.rfind("pcie.", 0) == 0                                 ? GM_HEALTH_WATCH_PCIE
                               : key.rfind("soak.", 0) == 0                                 ? GM_HEALTH_WATCH_POWER
                                                                                            : GM_HEALTH_WATCH_COMPUTE;
       if (h[i])
@@ -1310,6 +1385,7 @@ int cmd_expect(const Args& a, Report& r) {
     first = true;
     for (auto& kv : m.v) {
       const uint32_t system = kv.first.rfind("hbm.", 0) == 0 || kv.first.rfind("memtest.", 0) == 0 ? GM_HEALTH_WATCH_MEM
+                              : kv.first.rfind("pcie.", 0) == 0                                    ? GM_HEALTH_WATCH_PCIE
                               : kv.first.rfind("soak.", 0) == 0                                    ? GM_HEALTH_WATCH_POWER
                                                                                                     : GM_HEALTH_WATCH_COMPUTE;
       const std::string test = kv.first.substr(0, kv.first.find('.'));
@@ -1339,6 +1415,13 @@ int cmd_run(const Args& a, Report& r, const std::vector<int>& gpus, MfmaWatch* m
   sub.kv["--bytes"] = level == 1 ? "1G" : "4G";
   sub.kv["--iters"] = level == 1 ? "5" : "20";
   if ((rc = run_on(sub, r, gpus, [](const Args& x, Report& y, int g) { return cmd_hbm(x, y, g); }))) return rc;
+  {
+    // the host link: one GPU after the other, since the GPUs of a node share the host's memory and root ports
+    Args host = sub;
+    host.kv["--bytes"] = level == 1 ? "64M" : "256M";
+    host.kv["--iters"] = level == 1 ? "3" : "5";
+    if ((rc = run_on(host, r, gpus, [](const Args& x, Report& y, int g) { return cmd_pcie(x, y, g); }, /*one_at_a_time=*/true))) return rc;
+  }
   if (level < 3) sub.kv["--bytes"] = level == 1 ? "1G" : "16G";
   else sub.kv.erase("--bytes");
   if (level >= 2) sub.kv["--march"] = "1";
@@ -1370,10 +1453,11 @@ int cmd_run(const Args& a, Report& r, const std::vector<int>& gpus, MfmaWatch* m
 
 void usage() {
   fprintf(stderr,
-          "usage: gpumon-diag <info|expect|hbm|memtest|mfma|gemm|rccl|links|run> [options] [--json] [--publish FILE]\n"
+          "usage: gpumon-diag <info|expect|hbm|memtest|pcie|mfma|gemm|rccl|links|run> [options] [--json] [--publish FILE]\n"
           "  --publish FILE leaves the JSON report where `gpumon-exporter --diag-results` picks it up\n"
           "  hbm     [-g GPU | --gpus LIST|all] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
           "  memtest [-g GPU | --gpus LIST|all] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N] [--march]\n"
+          "  pcie    [-g GPU | --gpus LIST|all] [--bytes N] [--iters N] [--pcie-gen G --pcie-width W]   host link: copy engines and kernels over pinned memory\n"
           "  mfma    [-g GPU | --gpus LIST|all] [--dtype bf16|fp8|mxfp8|f32|all] [--seconds S]\n"
           "  gemm    [-g GPU | --gpus LIST|all] [--dtype LIST] [--m M --n N --k K] [--seconds S] [--check-every N] [--min-tflops X]\n"
           "          [--no-telemetry] [--mfma-counters]\n"
@@ -1469,7 +1553,7 @@ int main(int argc, char** argv) {
   if (wants_mfma && !have_mfma) fprintf(stderr, "note: gpumon-prof-probe not found next to this binary; no matrix-pipe counters\n");
   MfmaWatch* mw = have_mfma ? &mfma : nullptr;
   int rc;
-  const bool per_gpu = cmd == "hbm" || cmd == "memtest" || cmd == "mfma" || cmd == "gemm" || cmd == "run";
+  const bool per_gpu = cmd == "hbm" || cmd == "memtest" || cmd == "pcie" || cmd == "mfma" || cmd == "gemm" || cmd == "run";
   std::vector<int> gpus;
   if (per_gpu) {
     gpus = target_gpus(a);
@@ -1482,6 +1566,7 @@ int main(int argc, char** argv) {
   else if (cmd == "expect") rc = cmd_expect(a, r);
   else if (cmd == "hbm") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_hbm(x, y, g); });
   else if (cmd == "memtest") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_memtest(x, y, g); });
+  else if (cmd == "pcie") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_pcie(x, y, g); }, /*one_at_a_time=*/true);
   else if (cmd == "mfma") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_mfma(x, y, g); });
   else if (cmd == "gemm") rc = run_on(a, r, gpus, [mw](const Args& x, Report& y, int g) { return cmd_gemm(x, y, g, mw); });
   else if (cmd == "rccl") rc = cmd_rccl(a, r);

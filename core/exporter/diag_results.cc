@@ -50,6 +50,8 @@ const char* help_of(const std::string& fam) {
       {"gpumon_diag_node_timestamp_seconds", "Unix time of the last node-wide diagnostics report of this name."},
       {"gpumon_diag_test_health", "Verdict of one diagnostic test on one GPU (0 = pass, 10 = warning, 20 = failure)."},
       {"gpumon_diag_hbm_stream_tbps", "HBM stream bandwidth measured by the diagnostics (in TB/s)."},
+      {"gpumon_diag_pcie_gbps", "Host link bandwidth measured by the diagnostics over pinned memory, by traffic pattern (in GB/s)."},
+      {"gpumon_diag_pcie_link_gbps", "What one direction of the negotiated PCIe link carries at most (generation x width, in GB/s)."},
       {"gpumon_diag_memtest_errors", "Mismatching 64-bit words found by the HBM pattern test."},
       {"gpumon_diag_memtest_bytes", "Bytes of HBM covered by the pattern test."},
       {"gpumon_diag_mfma_peak_tflops", "Matrix-pipe peak measured on register operands (in TFLOP/s)."},
@@ -117,6 +119,11 @@ void parse_gpu_report(const Json& r, int gpu_index, Families* f) {
   if (const Json* ts = r.get("timestamp")) add("gpumon_diag_timestamp_seconds", "", num(ts));
   if (const Json* hbm = r.get("hbm_stream"))
     for (auto& kv : hbm->obj) add("gpumon_diag_hbm_stream_tbps", "kernel=\"" + kv.first + "\"", num(kv.second.get("tbps_best")));
+  if (const Json* pc = r.get("pcie")) {
+    for (const char* k : {"h2d", "d2h", "bidir", "kernel_read", "kernel_write"})
+      if (const Json* v = pc->get(std::string(k) + "_gbps")) add("gpumon_diag_pcie_gbps", std::string("traffic=\"") + k + "\"", num(v));
+    if (num(pc->get("link_gbps")) > 0) add("gpumon_diag_pcie_link_gbps", "", num(pc->get("link_gbps")));
+  }
   if (const Json* m = r.get("memtest")) {
     add("gpumon_diag_memtest_errors", "", num(m->get("errors")));
     add("gpumon_diag_memtest_bytes", "", num(m->get("bytes_tested")));

@@ -383,6 +383,31 @@ GMD_API int gmd_link_diagnose(int ndev, const double* uni, const double* bidi, c
  * is not available.  On MI355X each ordered pair is one xGMI link. */
 GMD_API int gmd_p2p_matrix(int ndev, const int* devices, uint64_t bytes, int iters, double* gbps);
 
+/* ------------------------------------------------------------- host link -- */
+/* The PCIe path between pinned host memory and one GPU, loaded five ways (diag/hip/pcie_test.hip): copy engines
+ * host-to-device, device-to-host and both at once; a kernel reading host memory and a kernel writing it.  Every
+ * transfer carries a pattern and is checked on the far side.  Rates are GB/s (1e9 bytes) of the best iteration. */
+typedef struct {
+  uint64_t bytes;      /* per transfer; 0 = 256 MiB */
+  int32_t iters;       /* <= 0: 5 */
+  int32_t verify;      /* check the data on the far side */
+  int32_t workgroups;  /* of the two kernels; <= 0: 1024 */
+  int32_t reserved;
+} gmd_pcie_config_t;
+typedef struct {
+  double h2d_gbps, d2h_gbps;              /* copy engines, one direction at a time */
+  double bidir_h2d_gbps, bidir_d2h_gbps;  /* both directions at once */
+  double kernel_read_gbps, kernel_write_gbps;
+  double small_h2d_us, small_d2h_us;      /* an 8-byte blocking copy, host clock, best of 56 */
+  uint64_t bad_h2d, bad_d2h, bad_kernel_read, bad_kernel_write;  /* 16-byte words that arrived wrong */
+  uint64_t bytes;
+  int32_t iters, verified;
+} gmd_pcie_result_t;
+GMD_API int gmd_pcie_test(int device, const gmd_pcie_config_t* cfg, gmd_pcie_result_t* out);
+/* What one direction of a link of that generation and width carries at most, GB/s (the reference's per-lane table,
+ * bindings/go/nvml/nvml.go:314-326, continued to generation 6); 0 for values outside the table. */
+GMD_API double gmd_pcie_link_gbps(int gen, int width);
+
 #ifdef __cplusplus
 }
 #endif

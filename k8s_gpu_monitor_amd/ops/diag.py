@@ -360,6 +360,37 @@ def link_fan_selftest(npeers=7, bytes=64 << 20, workgroups=0, iters=5, device=0)
     return list(g), list(b), _dict(r)
 
 
+class PcieConfig(C.Structure):
+    _fields_ = [("bytes", C.c_uint64), ("iters", C.c_int32), ("verify", C.c_int32), ("workgroups", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PcieResult(C.Structure):
+    _fields_ = [("h2d_gbps", C.c_double), ("d2h_gbps", C.c_double), ("bidir_h2d_gbps", C.c_double), ("bidir_d2h_gbps", C.c_double),
+                ("kernel_read_gbps", C.c_double), ("kernel_write_gbps", C.c_double), ("small_h2d_us", C.c_double), ("small_d2h_us", C.c_double),
+                ("bad_h2d", C.c_uint64), ("bad_d2h", C.c_uint64), ("bad_kernel_read", C.c_uint64), ("bad_kernel_write", C.c_uint64),
+                ("bytes", C.c_uint64), ("iters", C.c_int32), ("verified", C.c_int32)]
+
+
+def pcie_test(bytes=256 << 20, iters=5, verify=True, workgroups=0, device=0):
+    """The host link of one GPU over pinned memory: copy engines up, down and both at once, a kernel reading and a
+    kernel writing host memory; every transfer verified on the far side.  GB/s of the best iteration."""
+    L = _lib()
+    L.gmd_pcie_test.argtypes = [C.c_int, C.POINTER(PcieConfig), C.POINTER(PcieResult)]
+    cfg, r = PcieConfig(bytes, iters, int(verify), workgroups, 0), PcieResult()
+    rc = L.gmd_pcie_test(device, C.byref(cfg), C.byref(r))
+    if rc:
+        raise DiagError(rc, "gmd_pcie_test")
+    return _dict(r)
+
+
+def pcie_link_gbps(gen, width):
+    """What one direction of a PCIe link of that generation and width carries at most, GB/s."""
+    L = _lib()
+    L.gmd_pcie_link_gbps.restype = C.c_double
+    L.gmd_pcie_link_gbps.argtypes = [C.c_int, C.c_int]
+    return L.gmd_pcie_link_gbps(gen, width)
+
+
 def _expect(expect):
     e = LinkExpect()
     for k, v in (expect or {}).items():

@@ -371,6 +371,8 @@ def _diag_report(gpu=1, result="pass", copy_tbps=5.5, errors=0):
         "hbm_stream": {"read": {"tbps_best": 7.0, "tbps_median": 6.9, "verified": True},
                        "copy": {"tbps_best": copy_tbps, "tbps_median": 5.4, "verified": True}},
         "memtest": {"bytes_tested": 274877906944, "errors": errors},
+        "pcie": {"link_gen": 5, "link_width": 16, "link_gbps": 63.008, "h2d_gbps": 57.2, "d2h_gbps": 56.9, "bidir_gbps": 48.6,
+                 "kernel_read_gbps": 55.3, "kernel_write_gbps": 53.4, "bad_words": 0},
         "mfma_peak": {"bf16": {"tflops": 2179.5, "tflops_best": 2200.0}},
         "gemm_stress": {"bf16": {"tflops": 1450.0, "tflops_best": 1500.0, "launches": 900, "sdc_mismatches": 0,
                                  "mfma_active_avg": 71.7}},
@@ -404,6 +406,8 @@ def test_diag_report_becomes_metrics(engine2, tmp_path):
         assert by("gpumon_diag_hbm_stream_tbps")[(("gpu", "1"), ("kernel", "read"))] == 7.0
         assert by("gpumon_diag_memtest_bytes") == {(("gpu", "1"),): 274877906944.0}
         assert by("gpumon_diag_memtest_errors") == {(("gpu", "1"),): 0.0}
+        assert by("gpumon_diag_pcie_gbps")[(("gpu", "1"), ("traffic", "h2d"))] == 57.2 and len(by("gpumon_diag_pcie_gbps")) == 5
+        assert by("gpumon_diag_pcie_link_gbps") == {(("gpu", "1"),): 63.008}
         assert by("gpumon_diag_mfma_peak_tflops")[(("dtype", "bf16"), ("gpu", "1"))] == 2179.5
         assert by("gpumon_diag_gemm_tflops")[(("dtype", "bf16"), ("gpu", "1"))] == 1450.0
         assert by("gpumon_diag_gemm_sdc_mismatches")[(("dtype", "bf16"), ("gpu", "1"))] == 0.0

@@ -463,6 +463,35 @@ def test_link_test_kernels_and_the_one_gpu_case(diag):
     assert st["destinations"] == 7 and st["bad_words"] == 0 and 0 < st["window_ms_min"] <= st["window_ms_max"] <= st["launch_ms"] * 1.02 + 0.05
 
 
+def test_host_link_moves_and_verifies_data_at_the_rate_of_the_negotiated_link(diag):
+    """The PCIe path over pinned host memory, five ways; every transfer is checked on the far side.  The rates are held
+    against the negotiated link (generation x width from sysfs): a Gen5 x16 link carries 63 GB/s per direction and
+    the copy engines reach about nine tenths of it."""
+    r = diag.pcie_test(bytes=128 << 20, iters=3)
+    assert r["verified"] == 1 and r["bad_h2d"] == r["bad_d2h"] == r["bad_kernel_read"] == r["bad_kernel_write"] == 0, r
+    for k in ("h2d_gbps", "d2h_gbps", "bidir_h2d_gbps", "bidir_d2h_gbps", "kernel_read_gbps", "kernel_write_gbps"):
+        assert 5 < r[k] < 130, (k, r)   # something moved, and no faster than a Gen6 x16 link could
+    assert r["bidir_h2d_gbps"] + r["bidir_d2h_gbps"] > 1.2 * max(r["h2d_gbps"], r["d2h_gbps"]), r   # the directions do overlap
+    assert 1 < r["small_h2d_us"] < 500 and 1 < r["small_d2h_us"] < 500, r
+    assert diag.pcie_link_gbps(5, 16) == pytest.approx(63.008) and diag.pcie_link_gbps(3, 16) == pytest.approx(15.76)   # nvml.go:314-326
+    assert diag.pcie_link_gbps(0, 16) == 0 and diag.pcie_link_gbps(5, 0) == 0
+    with pytest.raises(diag.DiagError):
+        diag.pcie_test(bytes=1024)
+    rc, doc = _run_diag("pcie", "--bytes", "128M", "--iters", "3")
+    p = doc["pcie"]
+    assert p["bad_words"] == 0 and p["link_gen"] >= 3 and p["link_width"] >= 8, p
+    assert p["h2d_expected_gbps"] == pytest.approx(0.88 * p["link_gbps"], rel=1e-3)
+    assert p["h2d_gbps"] > 0.6 * p["link_gbps"] and p["kernel_read_gbps"] > 0.5 * p["link_gbps"], p
+    by = {v["test"]: v for v in doc["verdicts"]}
+    from k8s_gpu_monitor_amd import abi as A
+    assert by["pcie_link"]["system"] == A.HEALTH["PCIE"] and by["pcie_link"]["health"] in (0, 10), by
+    assert rc == 0
+    # the same link held against a generation it does not have: the test fails in the PCIe subsystem
+    rc, doc = _run_diag("pcie", "--bytes", "64M", "--iters", "2", "--pcie-gen", "6", "--pcie-width", "32")
+    by = {v["test"]: v for v in doc["verdicts"]}
+    assert rc == 1 and by["pcie_link"]["health"] == 20 and by["pcie_link"]["system"] == A.HEALTH["PCIE"], by
+
+
 def test_whole_link_test_rehearsed_with_one_card_in_four_positions():
     """Every pattern of the link test, both directions, the per-position buffers and the data checks, the grading and
     the report, with one card standing in four positions (its own memory plays the peers'): what a node with four GPUs
