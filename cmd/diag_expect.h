@@ -44,7 +44,7 @@ inline const std::vector<Table>& tables() {
        {6.5, 6.5, 6.5, 6.5, 6.8, 7.0}, 6.8, 6.5, 5.8,
        {2200, 2300, 150, 4700},
        {1550, 3000, 0, 3000},
-       {0.88, 0.88, 0.72, 0.82, 0.80},
+       {0.88, 0.88, 0.58, 0.82, 0.80},
        1700, 0.80,
        {95, 105}, {85, 95}, {0.01, 0.10}},
   };

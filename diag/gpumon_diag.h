@@ -396,8 +396,9 @@ typedef struct {
 } gmd_pcie_config_t;
 typedef struct {
   double h2d_gbps, d2h_gbps;              /* copy engines, one direction at a time */
-  double bidir_h2d_gbps, bidir_d2h_gbps;  /* both directions at once */
+  double bidir_h2d_gbps, bidir_d2h_gbps;  /* copy engines, both directions at once (whether they overlap is the runtime's choice of engines) */
   double kernel_read_gbps, kernel_write_gbps;
+  double duplex_read_gbps, duplex_write_gbps;  /* the two kernels at once: the link's rate with both directions busy */
   double small_h2d_us, small_d2h_us;      /* an 8-byte blocking copy, host clock, best of 56 */
   uint64_t bad_h2d, bad_d2h, bad_kernel_read, bad_kernel_write;  /* 16-byte words that arrived wrong */
   uint64_t bytes;

@@ -208,6 +208,32 @@ extern "C" int gmd_pcie_test(int device, const gmd_pcie_config_t* cfg_in, gmd_pc
   }
   if (verify) out->bad_kernel_write = host_check((const u32x4*)down.p, words, seed_kw);
 
+  // 3b. the link in both directions at once, driven by the two kernels on two streams: whether two copy-engine
+  //     transfers overlap is the runtime's choice of engines (on some hosts they run one after the other); two
+  //     kernels that fit on the chip together always do, so this is the link's duplex rate and not a scheduling fact
+  for (int it = 0; it < iters + 1; it++) {
+    float ms0 = 0, ms1 = 0;
+    GMD_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(unsigned long long), s0.s));
+    GMD_HIP(hipStreamSynchronize(s0.s));
+    GMD_HIP(hipEventRecord(a0.e, s0.s));
+    GMD_HIP(hipEventRecord(b0.e, s1.s));
+    pcie_check_kernel<<<grid / 2, 256, 0, s0.s>>>((const u32x4*)up_dev, words, seed_up, (unsigned long long*)d_bad.p);
+    pcie_fill_kernel<<<grid / 2, 256, 0, s1.s>>>((u32x4*)down_dev, words, seed_kw);
+    GMD_HIP(hipGetLastError());
+    GMD_HIP(hipEventRecord(a1.e, s0.s));
+    GMD_HIP(hipEventRecord(b1.e, s1.s));
+    GMD_HIP(hipEventSynchronize(a1.e));
+    GMD_HIP(hipEventSynchronize(b1.e));
+    GMD_HIP(hipEventElapsedTime(&ms0, a0.e, a1.e));
+    GMD_HIP(hipEventElapsedTime(&ms1, b0.e, b1.e));
+    if (it && gbps_of(ms0) + gbps_of(ms1) > out->duplex_read_gbps + out->duplex_write_gbps)
+      out->duplex_read_gbps = gbps_of(ms0), out->duplex_write_gbps = gbps_of(ms1);
+    unsigned long long v = 0;
+    GMD_HIP(hipMemcpy(&v, d_bad.p, sizeof v, hipMemcpyDeviceToHost));
+    out->bad_kernel_read += v;
+  }
+  if (verify) out->bad_kernel_write += host_check((const u32x4*)down.p, words, seed_kw);
+
   // 4. eight bytes each way, host clock around a blocking copy: what one small transfer costs
   {
     uint64_t word = 0;

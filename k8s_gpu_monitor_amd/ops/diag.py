@@ -366,7 +366,8 @@ class PcieConfig(C.Structure):
 
 class PcieResult(C.Structure):
     _fields_ = [("h2d_gbps", C.c_double), ("d2h_gbps", C.c_double), ("bidir_h2d_gbps", C.c_double), ("bidir_d2h_gbps", C.c_double),
-                ("kernel_read_gbps", C.c_double), ("kernel_write_gbps", C.c_double), ("small_h2d_us", C.c_double), ("small_d2h_us", C.c_double),
+                ("kernel_read_gbps", C.c_double), ("kernel_write_gbps", C.c_double), ("duplex_read_gbps", C.c_double), ("duplex_write_gbps", C.c_double),
+                ("small_h2d_us", C.c_double), ("small_d2h_us", C.c_double),
                 ("bad_h2d", C.c_uint64), ("bad_d2h", C.c_uint64), ("bad_kernel_read", C.c_uint64), ("bad_kernel_write", C.c_uint64),
                 ("bytes", C.c_uint64), ("iters", C.c_int32), ("verified", C.c_int32)]
 

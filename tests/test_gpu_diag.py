@@ -469,9 +469,12 @@ def test_host_link_moves_and_verifies_data_at_the_rate_of_the_negotiated_link(di
     the copy engines reach about nine tenths of it."""
     r = diag.pcie_test(bytes=128 << 20, iters=3)
     assert r["verified"] == 1 and r["bad_h2d"] == r["bad_d2h"] == r["bad_kernel_read"] == r["bad_kernel_write"] == 0, r
-    for k in ("h2d_gbps", "d2h_gbps", "bidir_h2d_gbps", "bidir_d2h_gbps", "kernel_read_gbps", "kernel_write_gbps"):
+    for k in ("h2d_gbps", "d2h_gbps", "bidir_h2d_gbps", "bidir_d2h_gbps", "kernel_read_gbps", "kernel_write_gbps", "duplex_read_gbps",
+              "duplex_write_gbps"):
         assert 5 < r[k] < 130, (k, r)   # something moved, and no faster than a Gen6 x16 link could
-    assert r["bidir_h2d_gbps"] + r["bidir_d2h_gbps"] > 1.2 * max(r["h2d_gbps"], r["d2h_gbps"]), r   # the directions do overlap
+    # with both directions busy the link carries more than one direction alone: by the two kernels, or by the two copy
+    # engines where the runtime lets them overlap
+    assert max(r["duplex_read_gbps"] + r["duplex_write_gbps"], r["bidir_h2d_gbps"] + r["bidir_d2h_gbps"]) > 1.2 * max(r["h2d_gbps"], r["d2h_gbps"]), r
     assert 1 < r["small_h2d_us"] < 500 and 1 < r["small_d2h_us"] < 500, r
     assert diag.pcie_link_gbps(5, 16) == pytest.approx(63.008) and diag.pcie_link_gbps(3, 16) == pytest.approx(15.76)   # nvml.go:314-326
     assert diag.pcie_link_gbps(0, 16) == 0 and diag.pcie_link_gbps(5, 0) == 0
