@@ -887,10 +887,14 @@ int cmd_gemm(const Args& a, Report& r, int gpu, MfmaWatch* mfma) {
            name.c_str(), m, n, k, gpu, g.tflops, g.tflops_best, want > 0 ? strprintf_local(", expected %.0f", want).c_str() : "",
            (unsigned long long)g.launches, g.seconds, (unsigned long long)g.sdc_mismatches, g.max_rel_err,
            g.verified > 0 ? "ok" : g.verified < 0 ? "WRONG" : "skipped");
+    if (g.verified)
+      r.text("  integrity: %llu launches summed in the kernel's epilogue and held against the first, %llu re-read from memory\n",
+             (unsigned long long)g.checked_in_kernel, (unsigned long long)g.checked_in_memory);
     obj += std::string(any ? "," : "") + "\"" + name + "\":{\"tflops\":" + jnum(g.tflops) + ",\"tflops_best\":" +
            jnum(g.tflops_best) + ",\"expected_tflops\":" + (want > 0 ? jnum(want) : "null") + ",\"launches\":" + std::to_string(g.launches) +
            ",\"sdc_mismatches\":" + std::to_string(g.sdc_mismatches) + ",\"max_rel_err\":" + jnum(g.max_rel_err) + ",\"verified\":" +
-           std::to_string(g.verified);
+           std::to_string(g.verified) + ",\"checked_in_kernel\":" + std::to_string(g.checked_in_kernel) + ",\"checked_in_memory\":" +
+           std::to_string(g.checked_in_memory);
     if (mfma) {  // the windows that lie inside this dtype's soak
       usleep(300000);  // let the window that ends with the soak arrive
       int wn = 0;

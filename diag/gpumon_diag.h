@@ -153,6 +153,8 @@ typedef struct {
   int32_t verified;     /* 1 = checksum / reference comparison passed, 0 = not checked, -1 = failed */
   uint64_t sdc_mismatches; /* launches whose checksum differed from the first launch */
   double max_rel_err;
+  uint64_t checked_in_kernel;  /* launches whose output was summed in the kernel's epilogue and held against the first */
+  uint64_t checked_in_memory;  /* launches followed by the checksum pass over C in memory */
 } gmd_mfma_result_t;
 
 /* Matrix-pipe peak: MFMAs on register-resident operands, no memory traffic. */
@@ -160,7 +162,10 @@ GMD_API int gmd_mfma_peak(int device, int dtype, double seconds, gmd_mfma_result
 /* GEMM stress: C[M,N] = A[M,K] * B[N,K]^T on random data for `seconds` (>= 1 launch).  With `verify`, the
  * first launch is compared with an independent reference (4096 sampled entries of C against full-K dot
  * products computed by a separate kernel in double precision: max_rel_err, tolerance 4e-3 of |ref| + rms) and
- * every later launch's output checksum with the first one's (silent-data-corruption check). */
+ * every later launch's output checksum with the first one's (silent-data-corruption check).  For whole-tile shapes
+ * the soak's kernel sums the words it stores on their way out (one atomic per wave), so EVERY launch is held against
+ * the first at no cost in throughput; the pass over C in memory, which also sees the stores and the memory cells,
+ * follows every `check_every`-th launch. */
 GMD_API int gmd_gemm_stress(int device, int dtype, int m, int n, int k, double seconds, int verify,
                             gmd_mfma_result_t* out);
 /* The same with every knob.  GEMMs go back to back into one stream with the host three batches ahead; the checksum

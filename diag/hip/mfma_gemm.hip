@@ -54,6 +54,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "diag_common.h"
@@ -165,6 +166,12 @@ __device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* _
 // columns, 16 bytes, and the sixteen lanes of one fq are one whole 256-byte row of the wave's tile: every quad of
 // lanes writes 64 contiguous bytes.  With store_acc's layout (neighbouring lanes = neighbouring ROWS) the address
 // path takes one lane per cycle: 7.9 k cycles for the 32 stores of four waves, cached or not, against 2 k at 64 B/clk.
+// EPI = 3 (the soak's instantiation): EPI = 1, and the words on their way out are summed on the side: per lane, then
+// over the wave, then one atomic per wave into g_gemm_reg_sum.  Identical operands give an identical sum launch after
+// launch, so the host can hold EVERY launch of a soak against the first without a pass over C in memory; what that
+// cannot see, a store or a memory cell that corrupts, the checksum pass over C (every Nth launch) still covers.
+__device__ unsigned long long g_gemm_reg_sum;
+
 template <int EPI, bool PACE = false>
 __device__ __forceinline__ void store_acc_rows(const f32x4 (&acc)[8][8], __bf16* __restrict__ C, size_t ldc, int row0, int col0,
                                                int fr, int fq) {
@@ -172,6 +179,7 @@ __device__ __forceinline__ void store_acc_rows(const f32x4 (&acc)[8][8], __bf16*
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   __bf16* const base = C + (size_t)(row0 + fq * 32) * ldc + col0 + fr * 8;
+  unsigned sum = 0;
 #pragma unroll
   for (int mb = 0; mb < 8; mb++) {
 #pragma unroll
@@ -181,11 +189,28 @@ __device__ __forceinline__ void store_acc_rows(const f32x4 (&acc)[8][8], __bf16*
       for (int h = 0; h < 4; h++)
         o[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{acc[mb][2 * h][r], acc[mb][2 * h + 1][r]}, bf16x2));
       u32x4* dst = (u32x4*)(base + (size_t)(r * 8 + mb) * ldc);
-      if constexpr (EPI == 1) __builtin_nontemporal_store(o, dst);
+      if constexpr (EPI == 1 || EPI == 3) __builtin_nontemporal_store(o, dst);
       else *dst = o;
+      if constexpr (EPI == 3) sum += (o[0] + o[1]) + (o[2] + o[3]);
     }
     if constexpr (PACE) __builtin_amdgcn_sched_barrier(0);
   }
+  if constexpr (EPI == 3) {
+    unsigned long long wide = sum;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) wide += __shfl_xor(wide, off, 64);
+    if (fr == 0 && fq == 0) atomicAdd(&g_gemm_reg_sum, wide);
+  }
+}
+
+// Test hook of the soak: one bit of an operand, flipped and flipped back around a single launch.
+__global__ void flip_bits_kernel(unsigned* p, unsigned mask) { *p ^= mask; }
+
+// Moves the soak's running sum to where the host reads it (pinned host memory) and starts the next batch from zero.
+__global__ void reg_sum_harvest_kernel(unsigned long long* dst) {
+  *dst = g_gemm_reg_sum;
+  g_gemm_reg_sum = 0;
+  __threadfence_system();
 }
 
 // store_acc_rows for a tile that reaches beyond M or N: the same stores, each behind its own bounds test.
@@ -2035,6 +2060,7 @@ struct GemmArgs {
   const uint32_t *sa, *sb;  // packed MX scales (MX-fp8 only)
   hipStream_t st;
   int ldc = 0;  // C's row stride in elements; 0 = n
+  bool reg_sum = false;  // the instantiation whose epilogue sums what it stores into g_gemm_reg_sum (reg_sum_shape())
 };
 int launch_lds(gemm_fn_t kfn, int grid, int threads, int lds_bytes, const GemmArgs& g) {
   // (a decomposed GEMM alternates between two kernels: the last two pairs are remembered)
@@ -2129,6 +2155,10 @@ int launch_gemm_t(const GemmArgs& g) {
     if (fp8_wide)
       return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 1, false, true, true>, grid, kThreadsW4, kLdsBytes, g);
     return launch_lds(gemm_w4_kernel<DT, 0, 1, false, true>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
+  }
+  if (g.reg_sum) {  // the soak: the default kernel of the data type with the summing epilogue (whole tiles, K-tile pairs)
+    if (fp8_wide) return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 3, false, false, true>, grid, kThreadsW4, kLdsBytes, g);
+    return launch_lds(gemm_w4_kernel<DT, 0, 3>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
   }
 #define GMD_LAUNCH(KFN, GRID, THREADS) return launch_lds(KFN, GRID, THREADS, kLdsBytes, g)
 #ifdef GMD_GEMM_ABLATE
@@ -2259,8 +2289,18 @@ int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles) {
 #endif
 }
 
+// Shapes the summing epilogue exists for: what the default schedule runs as whole 256 x 256 tiles over K-tile pairs on
+// the four-wave kernel (not the small-tile kernel, not the general instantiation), with no schedule asked for.
+static bool reg_sum_shape(int dtype, int m, int n, int k) {
+  const int asked = gemm_variant();
+  if (asked >= 0 && asked <= kVariantMax) return false;
+  const size_t ktiles = (size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB;
+  const int tiles128 = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
+  return m % BM == 0 && n % BN == 0 && ktiles >= 2 && ktiles % 2 == 0 && (dtype == GMD_DT_MXFP8 || tiles128 > persistent_grid());
+}
+
 static int gemm_launch_checked(int dtype, const void* a, const void* b, const void* sa, const void* sb, void* c, int m, int n, int k,
-                               void* hip_stream) {
+                               void* hip_stream, bool reg_sum = false) {
   // bf16 and fp8: M and N in multiples of 8 (a lane stores eight columns; rows are dealt to lanes in groups of eight);
   // MX-fp8: whole 256 x 256 tiles (the packed scales come in units of 128 rows and have no notion of a partial one).  K in whole 128-byte K-tiles.
   const int mn_step = dtype == GMD_DT_MXFP8 ? BM : 8;
@@ -2273,6 +2313,7 @@ static int gemm_launch_checked(int dtype, const void* a, const void* b, const vo
     return GMD_ERR_BADPARAM;
   }
   GemmArgs g{a, b, c, m, n, 0, (const uint32_t*)sa, (const uint32_t*)sb, (hipStream_t)hip_stream};
+  g.reg_sum = reg_sum;
   switch (dtype) {
     case GMD_DT_BF16:
       if (k % 64) return GMD_ERR_BADPARAM;
@@ -2404,6 +2445,45 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
   } rig;
   GMD_HIP(hipStreamCreateWithFlags(&rig.gemm, hipStreamNonBlocking));
   for (auto& e : rig.mark) GMD_HIP(hipEventCreate(&e));
+  // The register sum: every launch's output summed in the kernel's epilogue, harvested once per batch into pinned
+  // host memory (slot b % ring, read after batch b's mark), held against batch x (the sum of one launch).
+  // One sum per device and process: a second soak on the same card at the same time (two host threads on one GPU)
+  // goes without and relies on the pass over C.
+  static std::mutex soak_mu;
+  static int soaks_on_device[64];
+  struct Claim {
+    int dev;
+    bool first;
+    explicit Claim(int d) : dev(d & 63) {
+      std::lock_guard<std::mutex> l(soak_mu);
+      first = soaks_on_device[dev]++ == 0;
+    }
+    ~Claim() {
+      std::lock_guard<std::mutex> l(soak_mu);
+      soaks_on_device[dev]--;
+    }
+  } claim(device);
+  const bool reg = verify && claim.first && reg_sum_shape(dtype, m, n, k) && !getenv("GPUMON_GEMM_NO_REGSUM");
+  struct Pinned {
+    unsigned long long* p = nullptr;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+  } harvest;
+  unsigned long long* harvest_dev = nullptr;
+  unsigned long long reg_ref = 0;
+  if (reg) {
+    GMD_HIP(hipHostMalloc((void**)&harvest.p, (kMarkRing + 2) * sizeof(unsigned long long), hipHostMallocDefault));
+    GMD_HIP(hipHostGetDevicePointer((void**)&harvest_dev, harvest.p, 0));
+    reg_sum_harvest_kernel<<<1, 1, 0, rig.gemm>>>(harvest_dev + kMarkRing + 1);  // start from zero
+    if ((rc = gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, c.p, m, n, k, rig.gemm, true))) return rc;
+    reg_sum_harvest_kernel<<<1, 1, 0, rig.gemm>>>(harvest_dev + kMarkRing + 1);
+    GMD_HIP(hipGetLastError());
+    GMD_HIP(hipStreamSynchronize(rig.gemm));
+    reg_ref = harvest.p[kMarkRing + 1];
+    if (!reg_ref) {
+      gmd::set_error("GEMM stress: the kernel's own output sum is zero");
+      return GMD_ERR_VERIFY;
+    }
+  }
   const double flops = 2.0 * m * n * (double)k;
   const double t_start = now_s();
   double gpu_s = 0, best_ms = 1e30;
@@ -2431,19 +2511,32 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
     GMD_HIP(hipEventElapsedTime(&ms, e0, e1));
     gpu_s += ms * 1e-3;
     best_ms = std::min(best_ms, (double)ms / batch);
+    if (reg) {
+      if (harvest.p[b % (kMarkRing + 1)] != (unsigned long long)batch * reg_ref) out->sdc_mismatches++;
+      out->checked_in_kernel += batch;
+    }
     return GMD_OK;
   };
+  // $GPUMON_GEMM_INJECT_AT=N (tests): the exponent's top bit of A's first element is flipped for launch N alone, so
+  // that exactly one launch of the soak computes something else.
+  const char* inject_env = getenv("GPUMON_GEMM_INJECT_AT");
+  const long long inject_at = inject_env ? atoll(inject_env) : -1;
+  const unsigned inject_mask = dtype == GMD_DT_BF16 ? 0x4000u : 0x40u;
   GMD_HIP(hipEventRecord(rig.mark[0], rig.gemm));
   uint64_t settled = 0;  // batches 1..settled are accounted for
   for (;;) {
     for (int i = 0; i < batch; i++, launches++) {
-      if ((rc = gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, c.p, m, n, k, rig.gemm))) return rc;
+      if (inject_at >= 0 && ((long long)launches == inject_at || (long long)launches == inject_at + 1))
+        flip_bits_kernel<<<1, 1, 0, rig.gemm>>>((unsigned*)a.p, inject_mask);
+      if ((rc = gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, c.p, m, n, k, rig.gemm, reg))) return rc;
       if (verify && launches % check_every == 0) {
         checksum_kernel<<<1024, 256, 0, rig.gemm>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + in_window);
         in_window++;
+        out->checked_in_memory++;
       }
     }
     batches++;
+    if (reg) reg_sum_harvest_kernel<<<1, 1, 0, rig.gemm>>>(harvest_dev + batches % (kMarkRing + 1));
     GMD_HIP(hipEventRecord(rig.mark[batches % (kMarkRing + 1)], rig.gemm));
     // at most kRing - 1 batches in flight: the slot that the next mark takes has been read by then
     while (batches - settled >= (uint64_t)kMarkRing - 1) {

@@ -61,7 +61,8 @@ class MemtestConfig(C.Structure):
 class MfmaResult(C.Structure):
     _fields_ = [("tflops", C.c_double), ("tflops_best", C.c_double), ("seconds", C.c_double),
                 ("launches", C.c_uint64), ("clock_mhz_est", C.c_double), ("verified", C.c_int32),
-                ("sdc_mismatches", C.c_uint64), ("max_rel_err", C.c_double)]
+                ("sdc_mismatches", C.c_uint64), ("max_rel_err", C.c_double), ("checked_in_kernel", C.c_uint64),
+                ("checked_in_memory", C.c_uint64)]
 
 
 _typed = False

@@ -463,6 +463,38 @@ def test_link_test_kernels_and_the_one_gpu_case(diag):
     assert st["destinations"] == 7 and st["bad_words"] == 0 and 0 < st["window_ms_min"] <= st["window_ms_max"] <= st["launch_ms"] * 1.02 + 0.05
 
 
+def test_soak_holds_every_launch_against_the_first(diag):
+    """The soak's kernel sums the words it stores on their way out, so every launch is compared with the first at no cost
+    in throughput, next to the pass over C in memory after every 8th.  One launch that computes something else (an
+    operand bit flipped for that launch alone, between two passes over C) is caught by the in-kernel sum and by nothing
+    else."""
+    import json
+    import os
+    import subprocess
+    import sys
+    g = diag.gemm_stress("bf16", 8192, 8192, 8192, seconds=1.0)
+    assert g["verified"] == 1 and g["sdc_mismatches"] == 0
+    assert g["checked_in_kernel"] == g["launches"] and 0 < g["checked_in_memory"] <= g["launches"] // 8 + 1, g
+    small = diag.gemm_stress("bf16", 2048, 2048, 2048, seconds=0.3)   # the small-tile kernel has no summing epilogue
+    assert small["verified"] == 1 and small["checked_in_kernel"] == 0 and small["checked_in_memory"] > 0, small
+    code = ("import json; from k8s_gpu_monitor_amd.ops import diag\n"
+            "try:\n    g = diag.gemm_stress('%s', 4096, 4096, 4096, seconds=0.5)\n    print(json.dumps({'ok': True, 'sdc': g['sdc_mismatches']}))\n"
+            "except diag.DiagError as e:\n    print(json.dumps({'ok': False, 'msg': str(e)}))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dtype in ("bf16", "fp8"):
+        for env, caught in (({"GPUMON_GEMM_INJECT_AT": "3"}, True), ({"GPUMON_GEMM_INJECT_AT": "3", "GPUMON_GEMM_NO_REGSUM": "1"}, False),
+                            ({"GPUMON_GEMM_INJECT_AT": "16", "GPUMON_GEMM_NO_REGSUM": "1"}, True)):
+            r = subprocess.run([sys.executable, "-c", code % dtype], capture_output=True, text=True, timeout=120,
+                               env=dict(os.environ, PYTHONPATH=root, **env))
+            assert r.returncode == 0, r.stderr[-400:]
+            out = json.loads(r.stdout.strip().splitlines()[-1])
+            # launch 3 lies between two passes over C (launches 0 and 8): only the in-kernel sum sees it; launch 16 is
+            # followed by a pass over C and is seen either way
+            assert out["ok"] == (not caught), (dtype, env, out)
+            if caught:
+                assert "differ from the first" in out["msg"], out
+
+
 def test_host_link_moves_and_verifies_data_at_the_rate_of_the_negotiated_link(diag):
     """The PCIe path over pinned host memory, five ways; every transfer is checked on the far side.  The rates are held
     against the negotiated link (generation x width from sysfs): a Gen5 x16 link carries 63 GB/s per direction and
