@@ -240,3 +240,23 @@ exit 0
     assert cron["kind"] == "CronJob" and pod["restartPolicy"] == "Never" and pod["nodeSelector"] == {"hardware-type": "AMDGPU"}
     assert pod["containers"][0]["resources"]["limits"] == {"amd.com/gpu": 8}
     assert pod["volumes"][0]["hostPath"]["path"] == "/var/lib/gpumon/diag"
+
+
+def test_runbook_covers_every_alert_and_names_real_commands():
+    """docs/runbook.md has a row for every alert of the rule file, and the sub-commands it tells an operator to run exist."""
+    import re
+    import subprocess
+    rules = open(os.path.join(ROOT, "deploy", "docker", "prometheus", "gpumon-alerts.yml")).read()
+    book = open(os.path.join(ROOT, "docs", "runbook.md")).read()
+    alerts = re.findall(r"- alert: (\w+)", rules)
+    assert len(alerts) >= 20
+    missing = [a for a in alerts if f"`{a}`" not in book]
+    assert not missing, missing
+    usage = subprocess.run([os.path.join(ROOT, "build", "bin", "gpumon")], capture_output=True, text=True).stderr
+    known = set(re.search(r"<([a-z|]+)>", usage).group(1).split("|"))
+    for cmd in set(re.findall(r"`gpumon (\w+)", book)):
+        assert cmd in known, cmd
+    diag_usage = subprocess.run([os.path.join(ROOT, "build", "bin", "gpumon-diag")], capture_output=True, text=True).stderr
+    diag_known = set(re.search(r"<([a-z|]+)>", diag_usage).group(1).split("|"))
+    for cmd in set(re.findall(r"`gpumon-diag (\w+)", book)):
+        assert cmd in diag_known, cmd
