@@ -4,6 +4,9 @@
 // (plus the ASIC info); every optional one is absent, which the backend must take as "not supported".
 //
 //   STUB_GPUS        number of GPUs, one per socket (default 2); GPU i sits at 0000:<10+i>:00.0
+//   STUB_PARTITIONS  compute partitions per GPU (default 1): every socket then has that many processors, which share
+//                    the PCI address and differ in partition id, handed out in REVERSE order so that the backend's
+//                    sorting has something to do; the partition mode reads "CPX" (8), "QPX" (4), "DPX" (2) or "SPX"
 //   STUB_SYSFS       tree that holds bus/pci/devices/<bdf>/gpu_metrics (format 1 content 8), which this "library"
 //                    translates the way the real one does
 //   STUB_SKEW        added to the hotspot temperature the library reports (a decoding that differs from the file)
@@ -22,9 +25,9 @@
 
 namespace {
 
-struct Gpu { int index; } g_gpus[16];
+struct Gpu { int index, partition; } g_gpus[16 * 8];
 struct Socket { int index; } g_sockets[16];
-int g_n = 0;
+int g_n = 0, g_parts = 1;
 
 int env_int(const char* k, int d) {
   const char* v = getenv(k);
@@ -49,7 +52,12 @@ extern "C" {
 amdsmi_status_t amdsmi_init(uint64_t) {
   g_n = env_int("STUB_GPUS", 2);
   if (g_n < 0 || g_n > 16) g_n = 2;
-  for (int i = 0; i < g_n; i++) g_gpus[i].index = g_sockets[i].index = i;
+  g_parts = env_int("STUB_PARTITIONS", 1);
+  if (g_parts < 1 || g_parts > 8) g_parts = 1;
+  for (int i = 0; i < g_n; i++) {
+    g_sockets[i].index = i;
+    for (int p = 0; p < g_parts; p++) g_gpus[i * 8 + p] = Gpu{i, g_parts - 1 - p};
+  }
   return AMDSMI_STATUS_SUCCESS;
 }
 amdsmi_status_t amdsmi_shut_down(void) { return AMDSMI_STATUS_SUCCESS; }
@@ -63,8 +71,9 @@ amdsmi_status_t amdsmi_get_socket_handles(uint32_t* n, amdsmi_socket_handle* h) 
 }
 amdsmi_status_t amdsmi_get_processor_handles(amdsmi_socket_handle s, uint32_t* n, amdsmi_processor_handle* h) {
   if (!n || !s) return AMDSMI_STATUS_INVAL;
-  if (h && *n >= 1) h[0] = &g_gpus[static_cast<Socket*>(s)->index];
-  *n = 1;
+  if (h)
+    for (int p = 0; p < g_parts && p < (int)*n; p++) h[p] = &g_gpus[static_cast<Socket*>(s)->index * 8 + p];
+  *n = (uint32_t)g_parts;
   return AMDSMI_STATUS_SUCCESS;
 }
 amdsmi_status_t amdsmi_get_processor_type(amdsmi_processor_handle, processor_type_t* t) {
@@ -77,7 +86,18 @@ amdsmi_status_t amdsmi_get_gpu_device_bdf(amdsmi_processor_handle h, amdsmi_bdf_
   return AMDSMI_STATUS_SUCCESS;
 }
 amdsmi_status_t amdsmi_get_gpu_device_uuid(amdsmi_processor_handle h, unsigned int* len, char* uuid) {
-  snprintf(uuid, *len, "stub-%04d-0000-1000-8000-00000000%04d", static_cast<Gpu*>(h)->index, static_cast<Gpu*>(h)->index);
+  snprintf(uuid, *len, "stub-%04d-0000-1000-8000-0000%04d%04d", static_cast<Gpu*>(h)->index, static_cast<Gpu*>(h)->partition,
+           static_cast<Gpu*>(h)->index);
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_kfd_info(amdsmi_processor_handle h, amdsmi_kfd_info_t* k) {
+  memset(k, 0xff, sizeof *k);
+  k->current_partition_id = (uint32_t)static_cast<Gpu*>(h)->partition;
+  k->node_id = (uint32_t)(static_cast<Gpu*>(h)->index * 8 + static_cast<Gpu*>(h)->partition);
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_gpu_compute_partition(amdsmi_processor_handle, char* out, uint32_t len) {
+  snprintf(out, len, "%s", g_parts == 8 ? "CPX" : g_parts == 4 ? "QPX" : g_parts == 2 ? "DPX" : "SPX");
   return AMDSMI_STATUS_SUCCESS;
 }
 amdsmi_status_t amdsmi_get_gpu_asic_info(amdsmi_processor_handle, amdsmi_asic_info_t* a) {

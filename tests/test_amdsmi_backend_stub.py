@@ -187,3 +187,40 @@ def test_optional_sources_and_the_ras_chain_through_the_real_backend(stub, tmp_p
     assert np_["vram_total"][0] == 294896
     # 0 bytes used with the kernel counter present is a reading (the file exists in this tree)
     assert out["vram_zero"]["vram_used"][0] == 0
+
+
+PROBE_PARTITIONS = r"""
+import json
+from k8s_gpu_monitor_amd import engine as E
+from k8s_gpu_monitor_amd.utils.promparse import parse
+E.init(backend="amdsmi")
+out = {"devices": [(E.device_attributes(i)["pci_bdf"], E.device_attributes(i)["uuid"], E.device_mode(i)["compute_partition"]) for i in range(E.device_count())]}
+with E.Exporter(interval_ms=1000) as ex:
+    ex.sweep()
+    fams = parse(ex.render())
+out["labels"] = [l for l, _ in fams["dcgm_sm_clock"].samples]
+E.shutdown()
+print(json.dumps(out))
+"""
+
+
+def test_partitions_are_enumerated_in_order_and_labelled(stub, tmp_path, tables):
+    """A GPU in CPX-like mode shows up once per partition under one PCI address.  The library hands the partitions out
+    in whatever order; the backend sorts by address, then partition, and the exporter says which slice a series is."""
+    sysfs = tmp_path / "sys"
+    for i in range(2):
+        dev = sysfs / "bus" / "pci" / "devices" / f"0000:{0x10 + i:02x}:00.0"
+        dev.mkdir(parents=True)
+        (dev / "gpu_metrics").write_bytes(tables[i])
+    e = dict(os.environ, PYTHONPATH=ROOT, GPUMON_AMDSMI_LIB=str(stub), GPUMON_SYSFS_ROOT=str(sysfs), STUB_SYSFS=str(sysfs), STUB_GPUS="2",
+             STUB_PARTITIONS="4", GPUMON_PROC_ROOT=str(tmp_path / "noproc"))
+    e.pop("GPUMON_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", PROBE_PARTITIONS], capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode == 0, r.stderr[-800:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [d[0] for d in out["devices"]] == ["0000:10:00.0"] * 4 + ["0000:11:00.0"] * 4
+    assert len({d[1] for d in out["devices"]}) == 8 and all(d[2] == "QPX" for d in out["devices"])
+    # index order = address, then partition 0..3, although the library listed 3..0
+    assert [d[1][-8:-4] for d in out["devices"]] == ["0000", "0001", "0002", "0003"] * 2
+    assert [l["gpu"] for l in out["labels"]] == [str(i) for i in range(8)]
+    assert [l["partition"] for l in out["labels"]] == ["0", "1", "2", "3"] * 2

@@ -100,6 +100,10 @@ def test_standalone_client_full_api(daemon):
         E.fake_ctl("proc_add gpu=3 pid=99 name=job")
         time.sleep(0.3)
         assert E.pid_info(99)[0]["gpu"] == 3
+        # what the daemon's device layer says about its own sources travels too
+        assert E.process_source(3) == "fake" and E.metrics_table_source(3) == "n/a"
+        with pytest.raises(E.GpumonError):
+            E.metrics_table_source(64)
         i = E.introspect()
         assert i["memory_kb"] > 1000  # the DAEMON's memory, not ours
         with E.Exporter(interval_ms=200) as ex:  # an exporter can run against a remote engine too
