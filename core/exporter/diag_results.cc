@@ -57,6 +57,7 @@ const char* help_of(const std::string& fam) {
       {"gpumon_diag_mfma_peak_tflops", "Matrix-pipe peak measured on register operands (in TFLOP/s)."},
       {"gpumon_diag_gemm_tflops", "GEMM stress throughput on random data (in TFLOP/s)."},
       {"gpumon_diag_gemm_sdc_mismatches", "GEMM launches whose output checksum changed (silent data corruption)."},
+      {"gpumon_diag_gemm_checked_launches", "GEMM launches of the stress whose output was held against the first launch's: summed in the kernel, or re-read from memory."},
       {"gpumon_diag_soak_power_watts", "Board power during the GEMM soak (min / avg / max)."},
       {"gpumon_diag_soak_gfx_clock_mhz", "Shader clock held during the GEMM soak (min / avg / max)."},
       {"gpumon_diag_soak_gpu_temp_celsius", "Hotspot temperature during the GEMM soak (min / avg / max)."},
@@ -134,6 +135,10 @@ void parse_gpu_report(const Json& r, int gpu_index, Families* f) {
     for (auto& kv : g->obj) {
       add("gpumon_diag_gemm_tflops", "dtype=\"" + kv.first + "\"", num(kv.second.get("tflops")));
       add("gpumon_diag_gemm_sdc_mismatches", "dtype=\"" + kv.first + "\"", num(kv.second.get("sdc_mismatches")));
+      if (kv.second.get("checked_in_kernel")) {
+        add("gpumon_diag_gemm_checked_launches", "dtype=\"" + kv.first + "\",how=\"kernel\"", num(kv.second.get("checked_in_kernel")));
+        add("gpumon_diag_gemm_checked_launches", "dtype=\"" + kv.first + "\",how=\"memory\"", num(kv.second.get("checked_in_memory")));
+      }
       if (kv.second.get("mfma_active_avg"))
         add("gpumon_diag_gemm_mfma_active_percent", "dtype=\"" + kv.first + "\"", num(kv.second.get("mfma_active_avg")));
     }

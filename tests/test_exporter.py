@@ -375,7 +375,7 @@ def _diag_report(gpu=1, result="pass", copy_tbps=5.5, errors=0):
                  "kernel_read_gbps": 55.3, "kernel_write_gbps": 53.4, "bad_words": 0},
         "mfma_peak": {"bf16": {"tflops": 2179.5, "tflops_best": 2200.0}},
         "gemm_stress": {"bf16": {"tflops": 1450.0, "tflops_best": 1500.0, "launches": 900, "sdc_mismatches": 0,
-                                 "mfma_active_avg": 71.7}},
+                                 "checked_in_kernel": 896, "checked_in_memory": 113, "mfma_active_avg": 71.7}},
         "mfma_active": {"min": 69.1, "avg": 70.2, "max": 71.4, "clock_mhz": 1940.0, "windows": 18},
         "telemetry": {"power": {"min": 900.0, "avg": 1350.5, "max": 1400.0, "samples": 50},
                       "gfx_clock": {"min": 2100.0, "avg": 2180.0, "max": 2400.0, "samples": 50}},
@@ -411,6 +411,8 @@ def test_diag_report_becomes_metrics(engine2, tmp_path):
         assert by("gpumon_diag_mfma_peak_tflops")[(("dtype", "bf16"), ("gpu", "1"))] == 2179.5
         assert by("gpumon_diag_gemm_tflops")[(("dtype", "bf16"), ("gpu", "1"))] == 1450.0
         assert by("gpumon_diag_gemm_sdc_mismatches")[(("dtype", "bf16"), ("gpu", "1"))] == 0.0
+        assert by("gpumon_diag_gemm_checked_launches")[(("dtype", "bf16"), ("gpu", "1"), ("how", "kernel"))] == 896.0
+        assert by("gpumon_diag_gemm_checked_launches")[(("dtype", "bf16"), ("gpu", "1"), ("how", "memory"))] == 113.0
         assert by("gpumon_diag_soak_power_watts")[(("gpu", "1"), ("stat", "avg"))] == 1350.5
         assert by("gpumon_diag_soak_mfma_active_percent")[(("gpu", "1"), ("stat", "max"))] == 71.4
         assert by("gpumon_diag_gemm_mfma_active_percent")[(("dtype", "bf16"), ("gpu", "1"))] == 71.7
