@@ -33,6 +33,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <thread>
 
 #include "../diag/gpumon_diag.h"
@@ -752,7 +753,7 @@ struct Soak {
     gm_group_create(name.c_str(), &group);
     gm_group_add_device(group, gpu);
     gm_field_group_create(ids, 8, name.c_str(), &fg);
-    gm_watch_fields(group, fg, 100000, 600.0, 0);
+    gm_watch_fields(group, fg, 100000, 7200.0, 0);
     gm_update_all_fields(1);
     struct timespec ts;
     clock_gettime(CLOCK_REALTIME, &ts);
@@ -774,7 +775,7 @@ struct Soak {
     r.text("  telemetry during the run (100 ms samples):\n");
     bool first = true;
     for (auto& f : fs) {
-      std::vector<gm_value_t> v(8192);
+      std::vector<gm_value_t> v(65536);  // 100 ms samples: close to two hours
       int n = (int)v.size();
       if (gm_values_since(gpu, f.id, t0, v.data(), &n) != GM_ST_OK) continue;
       Stat st;
@@ -872,7 +873,29 @@ int cmd_gemm(const Args& a, Report& r, int gpu, MfmaWatch* mfma) {
     cfg.check_every = (int)a.num("--check-every", 0);
     gmd_mfma_result_t g;
     const double t_begin = MfmaWatch::now();
+    // A long soak says every half minute that it is alive and what the part is doing (stderr: the report stays clean).
+    std::atomic<bool> beat_stop{false};
+    std::thread beat;
+    if (secs >= 45)
+      beat = std::thread([&] {
+        for (int t = 30;; t += 30) {
+          for (int i = 0; i < 300 && !beat_stop; i++) usleep(100000);
+          if (beat_stop) return;
+          std::string now;
+          if (soak.on) {
+            const uint16_t ids[3] = {GM_FI_POWER_USAGE, GM_FI_GFX_CLOCK, GM_FI_GPU_TEMP};
+            gm_value_t v[3];
+            if (gm_latest_values(soak.gpu, ids, 3, v) == GM_ST_OK) {
+              auto num = [](const gm_value_t& x) { return x.status != GM_VS_OK ? NAN : x.type == GM_FT_DOUBLE ? x.v.dbl : (double)x.v.i64; };
+              now = strprintf_local(": %.0f W, %.0f MHz, %.0f C", num(v[0]), num(v[1]), num(v[2]));
+            }
+          }
+          fprintf(stderr, "  %s soak on GPU %d, %d of %.0f s%s\n", name.c_str(), gpu, t, secs, now.c_str());
+        }
+      });
     int rc = gmd_gemm_stress_run(&cfg, &g);
+    beat_stop = true;
+    if (beat.joinable()) beat.join();
     const double t_end = MfmaWatch::now();
     loaded_s += t_end - t_begin;
     if (rc != GMD_OK && rc != GMD_ERR_VERIFY) {
