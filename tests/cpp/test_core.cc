@@ -3,6 +3,9 @@
 // the sampler <-> reader hand-off, concurrent control-plane calls, the RPC
 // server with several clients, and the text parsers on hostile input.
 // Plain asserts; no test framework.
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -446,6 +449,91 @@ static void test_prof_child() {
 }
 
 // -- refcount + direct layer ------------------------------------------------------
+// -- the exporter's threads against each other ----------------------------------
+// Sweeps at the 100 ms floor (one with a file sink, one that only keeps the latch), the pod-map thread re-reading a
+// file that changes under it, the health check, and scrapers that render on demand: everything that touches the
+// exporter's state at once.
+static std::string http_get(int port, const char* path) {
+  int fd = socket(AF_INET, SOCK_STREAM, 0);
+  CHECK(fd >= 0);
+  sockaddr_in sa;
+  memset(&sa, 0, sizeof sa);
+  sa.sin_family = AF_INET;
+  sa.sin_port = htons((uint16_t)port);
+  sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+  CHECK(connect(fd, (sockaddr*)&sa, sizeof sa) == 0);
+  const std::string req = std::string("GET ") + path + " HTTP/1.0\r\n\r\n";
+  CHECK(write(fd, req.data(), req.size()) == (ssize_t)req.size());
+  std::string body;
+  char buf[65536];
+  ssize_t n;
+  while ((n = read(fd, buf, sizeof buf)) > 0) body.append(buf, (size_t)n);
+  close(fd);
+  return body;
+}
+
+static void test_exporter_threads() {
+  init_fake("gpus=4,seed=3");
+  char dir[] = "/tmp/gpumon-cpp-XXXXXX";
+  CHECK(mkdtemp(dir));
+  const std::string out = std::string(dir) + "/dcgm.prom", map = std::string(dir) + "/pods.tsv", state = std::string(dir) + "/state.json";
+  auto write_map = [&](int gen) {
+    std::string text;
+    for (int g = 0; g < 4; g++) text += strprintf("amdgpu%d\tpod-%d-%d\tns%d\tmain\n", g, g, gen, gen % 3);
+    CHECK(write_file_atomic(map, text.data(), text.size()));
+  };
+  write_map(0);
+  gm_exporter_t ex[2];
+  for (int i = 0; i < 2; i++) {
+    gm_exporter_config_t c;
+    memset(&c, 0, sizeof c);
+    c.version = GM_EXPORTER_CONFIG_VERSION;
+    c.profiling = c.amd_extras = c.self_metrics = c.health = 1;
+    c.interval_ms = 100;
+    c.slow_interval_ms = 300;
+    c.pod_refresh_ms = 100;
+    c.listen = "127.0.0.1:0";
+    c.pod_map_path = map.c_str();
+    if (i == 0) c.output_path = out.c_str(), c.state_path = state.c_str();
+    OK(gm_exporter_create(&c, &ex[i]));
+    OK(gm_exporter_start(ex[i]));
+  }
+  int port[2];
+  for (int i = 0; i < 2; i++) OK(gm_exporter_http_port(ex[i], &port[i]));
+  std::atomic<bool> stop{false};
+  std::atomic<int> scrapes{0}, with_pods{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < 4; t++)
+    th.emplace_back([&, t] {
+      while (!stop) {
+        const std::string body = http_get(port[t & 1], t < 2 ? "/metrics" : "/gpu/metrics");
+        CHECK(body.find("200 OK") != std::string::npos && body.find("dcgm_gpu_temp{gpu=\"3\"") != std::string::npos);
+        if (body.find("pod_name=\"pod-") != std::string::npos) with_pods++;
+        scrapes++;
+      }
+    });
+  th.emplace_back([&] {  // the node changes under the exporters
+    for (int gen = 1; !stop; gen++) {
+      write_map(gen);
+      gm_fake_ctl(gen & 1 ? "load gpu=1 util=90" : "load gpu=1 util=0");
+      gm_fake_ctl(gen % 5 == 0 ? "ecc gpu=2 ue=1" : "set gpu=0 field=150 value=55");
+      usleep(20000);
+    }
+  });
+  usleep(1500000);
+  stop = true;
+  for (auto& t : th) t.join();
+  for (int i = 0; i < 2; i++) {
+    OK(gm_exporter_stop(ex[i]));
+    OK(gm_exporter_destroy(ex[i]));
+  }
+  std::string text;
+  CHECK(read_file(out, &text) && text.find("dcgm_gpu_last_not_idle_time{gpu=\"1\"") != std::string::npos);
+  CHECK(scrapes > 20 && with_pods > 0);
+  OK(gm_shutdown());
+  printf("exporter threads: %d scrapes (%d with pod labels) against two exporters at the 100 ms floor ok\n", scrapes.load(), with_pods.load());
+}
+
 static void test_lifecycles() {
   CHECK(gm_shutdown() == GM_ST_UNINITIALIZED);
   init_fake("gpus=2");
@@ -489,6 +577,7 @@ int main() {
   test_parsers();
   test_prof_child();
   test_concurrent_engine();
+  test_exporter_threads();
   test_rpc();
   printf("ALL OK\n");
   return 0;
