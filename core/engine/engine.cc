@@ -542,8 +542,11 @@ void LocalEngine::ensure_internal_watch(const std::string& key, const std::vecto
     w.gpus = gpus;
     w.fields = fields;
     w.freq_us = freq_us;
+    // The engine's own consumers (status, health, policy, accounting, the RAS baseline) read the latest value and
+    // keep what they compare with themselves: two samples, not five minutes of them.  A caller's watch on the same
+    // field that asks for more still gets it (rebuild_watch_table: the larger retention wins).
     w.keep_age_us = (int64_t)(GM_DEFAULT_MAX_KEEP_AGE_S * 1e6);
-    w.keep_samples = 0;
+    w.keep_samples = 2;
     internal_watches_[key] = w;
   }
   rebuild_watch_table();

@@ -59,6 +59,7 @@ def main():
     try:
         time.sleep(1.5)  # first sweep done, static attributes cached
         ex.scrape()
+        rss0 = ex.rss_kb()
         cpu0, t0 = ex.cpu_seconds(), time.perf_counter()
         lat, body = [], b""
         period = 1.0 / a.scrape_hz
@@ -66,6 +67,8 @@ def main():
         while time.perf_counter() - t0 < a.seconds:
             ms, body = ex.scrape()
             lat.append(ms)
+            if len(lat) % max(1, int(30 * a.scrape_hz)) == 0:  # a long run says that it is alive
+                print(f"scrape_bench: {time.perf_counter() - t0:.0f} s, {len(lat)} scrapes, RSS {ex.rss_kb()} kB", flush=True)
             nxt += period
             time.sleep(max(0.0, nxt - time.perf_counter()))
         wall = time.perf_counter() - t0
@@ -80,7 +83,7 @@ def main():
             "scrape_ms": {"p50": round(statistics.median(lat), 3), "p90": round(pct(lat, 0.9), 3),
                           "p99": round(pct(lat, 0.99), 3), "max": round(max(lat), 3)},
             "exporter_cpu_percent_of_one_core": round(100 * cpu / wall, 3),
-            "exporter_rss_kb": ex.rss_kb(), "body_bytes": len(body), "families": len(fams), "series": series,
+            "exporter_rss_kb": ex.rss_kb(), "exporter_rss_kb_at_start": rss0, "body_bytes": len(body), "families": len(fams), "series": series,
             "self_metrics": self_metrics,
             "targets": {"scrape_p50_ms": 50, "cpu_percent": 1.0},
         }

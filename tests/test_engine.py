@@ -1,6 +1,7 @@
 """Host engine core on the fake backend: lifecycle, groups, field groups,
 watches, retention, snapshot reads, injection, status, introspection."""
 import threading
+import os
 import time
 
 import pytest
@@ -202,6 +203,41 @@ def test_watches_registered_apart_share_sample_cycles(engine):
     gaps = [b - a for a, b in zip(ecc, ecc[1:])]
     assert 150_000 < sum(gaps) / len(gaps) < 250_000, gaps  # the period of the second watch is kept
     assert len(set(ecc[-5:]) & set(temp)) >= 4  # and its samples carry the first watch's time stamps
+
+
+def test_the_engines_own_watches_do_not_hoard_samples():
+    """Health, policy, status and accounting read the latest value only.  Their internal watches must not turn a fast
+    caller's watch (two samples kept, as the exporter asks) into five minutes of history per field: at 1 kHz that is
+    ten megabytes a second (measured before internal watches were held to two samples: +26 MB in 2.5 s).  In a process
+    of its own, so that the resident size is the engine's and not the test runner's heap."""
+    import json
+    import subprocess
+    import sys
+    code = r"""
+import json, time
+from k8s_gpu_monitor_amd import engine as E, abi as A
+E.init(backend="fake", backend_spec="gpus=8")
+g = E.group_create("h", list(range(8)))
+E.health_set(g)                      # internal watch over some twenty fields of every GPU
+for i in range(8):
+    E.device_status(i)               # and the persistent status watch
+fields = [f for f in E.field_list() if not E.field_meta(f)["is_static"]]
+fg = E.field_group_create("h", fields)
+E.watch_fields(g, fg, update_freq_us=1000, max_keep_age_s=300, max_keep_samples=2)
+time.sleep(0.3)
+b = E.introspect()
+time.sleep(2.5)
+a = E.introspect()
+print(json.dumps({"grown_kb": a["memory_kb"] - b["memory_kb"], "cycles": a["sample_cycles"] - b["sample_cycles"],
+                  "kept": len(E.values_since(0, A.FI["GPU_TEMP"]))}))
+E.shutdown()
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr[-500:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["cycles"] > 500 and out["kept"] == 2, out
+    assert out["grown_kb"] < 3000, out
 
 
 def test_one_bulk_read_serves_many_fields(engine):
