@@ -294,7 +294,15 @@ void Exporter::refresh_pod_map() {
     gm_status_t st = kubelet_->list(10000, &m, &err);
     kubelet_connects_ = kubelet_->connects();
     ok = st == GM_ST_OK;
-    if (!ok) GM_LOGW("pod attribution: kubelet query failed: %s", err.c_str());
+    // Said when it starts failing, once a minute while it keeps failing, and when it works again: a kubelet that is
+    // down for an hour is two lines and sixty reminders, not one line per query.
+    const int64_t now = monotonic_us();
+    if (!ok && (!kubelet_failing_ || now - kubelet_warned_mono_ > 60 * 1000000ll)) {
+      GM_LOGW("pod attribution: kubelet query failed: %s%s", err.c_str(), kubelet_failing_ ? " (still)" : "");
+      kubelet_warned_mono_ = now;
+    }
+    if (ok && kubelet_failing_) GM_LOGI("pod attribution: the kubelet answers again");
+    kubelet_failing_ = !ok;
   }
   if (!ok && !cfg_.pod_map_path.empty()) {
     std::string text;

@@ -124,6 +124,8 @@ class Exporter {
   std::map<uint32_t, int64_t> last_not_idle_;
   std::vector<std::string> proc_source_;  // per exported GPU, refreshed once a minute (render_self)
   int64_t proc_source_mono_ = 0;
+  bool kubelet_failing_ = false;   // pod thread only
+  int64_t kubelet_warned_mono_ = 0;
   bool state_dirty_ = false;
   int64_t state_saved_mono_ = 0;
   PodMap pod_map_;
