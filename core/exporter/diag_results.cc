@@ -40,6 +40,8 @@ struct CachedReport {
   std::vector<Pending> verdicts;
   bool submitted_ok = false;      // every verdict was accepted by the engine
   int64_t submitted_mono_us = 0;  // when that last happened
+  int64_t attempt_mono_us = 0;    // when they were last offered, accepted or not
+  bool said = false;              // what there is to complain about in this report has been said once
 };
 
 const char* help_of(const std::string& fam) {
@@ -254,23 +256,25 @@ std::map<std::string, CachedReport> g_cache;
 
 // Hands the report's verdicts to the engine.  True when every one of them was accepted (or is about a card the
 // engine does not have, which no retry will change).
-bool submit_verdicts(const CachedReport& c, const std::string& file, Resolver& resolve, Engine* engine) {
+bool submit_verdicts(CachedReport& c, const std::string& file, Resolver& resolve, Engine* engine) {
   bool ok = true;
   for (auto& p : c.verdicts) {
     const int idx = resolve(p.pci_bdf, p.report_gpu);
     if (idx < 0) {
-      GM_LOGW("exporter: %s: verdict %s is about GPU %d (%s), which is not one of the engine's; not submitted", file.c_str(), p.d.test, p.report_gpu,
-              p.pci_bdf.c_str());
+      if (!c.said)
+        GM_LOGW("exporter: %s: verdict %s is about GPU %d (%s), which is not one of the engine's; not submitted", file.c_str(), p.d.test, p.report_gpu,
+                p.pci_bdf.c_str());
       continue;
     }
     gm_diag_result_t d = p.d;
     d.gpu = (uint32_t)idx;
     gm_status_t st = engine->diag_submit(d);
     if (st != GM_ST_OK) {
-      GM_LOGW("exporter: diagnostics verdict %s of GPU %u not accepted (%d); will be offered again", d.test, d.gpu, (int)st);
+      if (!c.said) GM_LOGW("exporter: diagnostics verdict %s of GPU %u not accepted (%d); will be offered again", d.test, d.gpu, (int)st);
       ok = false;
     }
   }
+  c.said = true;  // once per report: the retries that follow are silent
   return ok;
 }
 
@@ -292,7 +296,9 @@ void load(const std::string& file, Families* merged, Engine* engine, Resolver& r
   // Offered until accepted, and again once a minute after that: an engine that was away when the report appeared,
   // or that has restarted since and lost what it was told, ends up with the verdicts that are on disk.
   const int64_t now = monotonic_us();
-  if (engine && !c.verdicts.empty() && (!c.submitted_ok || now - c.submitted_mono_us >= 60000000)) {
+  const bool due = c.submitted_ok ? now - c.submitted_mono_us >= 60000000 : !c.attempt_mono_us || now - c.attempt_mono_us >= 5000000;
+  if (engine && !c.verdicts.empty() && due) {  // a refusal is retried every five seconds, not at every render
+    c.attempt_mono_us = now;
     c.submitted_ok = submit_verdicts(c, file, resolve, engine);
     if (c.submitted_ok) c.submitted_mono_us = now;
   }

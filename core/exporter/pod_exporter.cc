@@ -41,8 +41,8 @@ bool PodExporter::rewrite_once(std::string* error) {
       last_map_us_ = now;
       kubelet_failures_ = 0;
     } else {
-      kubelet_failures_++;
-      GM_LOGW("failed to get devices Pod information: %s", err.c_str());
+      // the first failure of a row, then every sixtieth: one line a minute at the default one-second sweep
+      if (kubelet_failures_++ % 60 == 0) GM_LOGW("failed to get devices Pod information: %s", err.c_str());
       if (!have_map_) {
         if (error) *error = err;
         return false;
