@@ -574,6 +574,14 @@ gm_status_t Exporter::publish() {
   if (cfg_.health) check_health();
   if (cfg_.output_path.empty()) {
     update_latch();
+    // Reports of the diagnostics are read, and their verdicts handed to the engine, when the text is rendered; with
+    // no file to write that would wait for the next scrape.  Once a second is soon enough for a health incident.
+    const int64_t now = monotonic_us();
+    if (!cfg_.diag_results_path.empty() && now - diag_polled_mono_ >= 1000000) {
+      diag_polled_mono_ = now;
+      std::string unused;
+      render_diag_results(cfg_.diag_results_path, &unused, engine_);
+    }
   } else {
     std::string text;
     render(&text);

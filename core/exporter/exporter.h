@@ -124,6 +124,7 @@ class Exporter {
   std::map<uint32_t, int64_t> last_not_idle_;
   std::vector<std::string> proc_source_;  // per exported GPU, refreshed once a minute (render_self)
   int64_t proc_source_mono_ = 0;
+  int64_t diag_polled_mono_ = 0;   // publish thread only
   bool kubelet_failing_ = false;   // pod thread only
   int64_t kubelet_warned_mono_ = 0;
   bool state_dirty_ = false;

@@ -68,3 +68,23 @@ def test_narrow_counters_keep_their_not_reported_marker(pairs):
 
 def test_other_backends_have_no_table(engine):
     assert E.metrics_table_source(0) == "n/a"
+
+
+def test_any_bytes_decode_or_are_refused_never_crash(pairs):
+    """Whatever the driver's file holds, the decoder answers with a table or a reason."""
+    from hypothesis import given, settings, strategies as st
+    good = bytes.fromhex(pairs[0]["raw"])
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.binary(min_size=0, max_size=4200), st.integers(0, 3871), st.binary(min_size=1, max_size=64))
+    def run(blob, at, patch):
+        for raw in (blob, good[:at] + patch + good[at + len(patch):]):
+            try:
+                m = E.metrics_table_decode(raw)
+            except ValueError as e:
+                assert str(e)
+                continue
+            assert len(m["xcp_stats"]) == 8 and len(m["current_gfxclks"]) == 8
+            assert all(0 <= v <= U64 for v in m["xgmi_read_data_acc"])
+
+    run()
