@@ -202,10 +202,16 @@ GMD_API int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int r
  * 7 = schedule 2 on the K=32 instruction for unscaled fp8 (2 for the other data types).
  * 8 = 128 x 128 tiles, four waves of 64 x 64, two workgroups per CU (bf16 and fp8, any M, N in multiples of 8): what
  * the default picks where the 256 x 256 tiles cannot fill the chip (2048^3 is 64 of them on 256 CUs); MX-fp8 runs 2.
- * All schedules give
+ * 9 = schedule 8 split along K: where the small tiles fill at most half of the CUs, several workgroups share a tile, each
+ * over a range of K-tiles, and a second kernel adds their fp32 sums up in a fixed order (the default takes it from
+ * 32 K-tiles on, 1024 x 1024 x 4096; asked for, it splits whatever has two K-tiles; otherwise 8 runs).
+ * All schedules but 9 give
  * bit-identical results, except that unscaled fp8 has two groups of them, one per MFMA instruction (K=128: -1, 2, 6, 8;
- * K=32: the others), whose sums differ in the order of their additions.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
+ * K=32: the others), whose sums differ in the order of their additions; a split GEMM adds the same products in
+ * another order again, the same one at every launch.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
+/* Number of K ranges into which the schedule in force splits a GEMM of this shape on the current device (1 = no split). */
+GMD_API int gmd_gemm_split_k(int dtype, int m, int n, int k);
 
 /* Timing-only ablation builds (make diag-ablate): per-workgroup pairs (shader-clock ticks,
  * 100 MHz real-time ticks) of the last launch of a stamped variant.  GMD_ERR_UNSUPPORTED in

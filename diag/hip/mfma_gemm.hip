@@ -54,8 +54,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "diag_common.h"
 
@@ -1808,7 +1810,8 @@ double peak_flops_per_mfma(int dt) {
 // K=128 schedules'.  A 64 x 64 wave tile reads 8 fragments per 16 MFMAs, which is all the LDS can deliver, so this is
 // no kernel for large problems; the dispatcher uses it where the large tiles cannot fill the chip.
 // Any M, any N that is a multiple of 8, whole K-tiles: rows beyond the matrix are fetched from its last row and
-// their results are not stored.
+// their results are not stored.  The SPLIT instantiation walks a range of the K-tiles and leaves its accumulators in a
+// workspace instead of storing C (split_k_count() below says when).
 constexpr int kS128 = 128;
 constexpr int kS128Threads = 256;
 constexpr int kS128TileBytes = kS128 * BKB;  // 16 KiB per operand per stage
@@ -1827,11 +1830,42 @@ struct S128Args {
   int tiles0;
   int ldc;
   size_t row_bytes;
+  // Split along K (SPLIT instantiation, region 0 only): workgroup b computes K-tiles [s * kt_per_split, ...) of tile
+  // b % tiles0 with s = b / tiles0 and leaves its fp32 accumulators in `work` for gemm_s128_reduce_kernel.
+  float* work;
+  int kt_per_split;
 };
 
-template <int DT, int NSTAGE = kS128Stages>
+// A wave's accumulators in the split workspace: one 16-byte word per lane and 16 x 16 block, so that a wave's store or
+// load of a block is one contiguous KiB.  Slab (split, tile, wave) holds 16 blocks (mb * 4 + nb).
+constexpr size_t kS128SlabFloats = 16 * 64 * 4;  // per wave
+__device__ __forceinline__ f32x4* s128_slab(float* work, int split, int tiles, int tile, int wave) {
+  return (f32x4*)(work + (((size_t)split * tiles + tile) * 4 + wave) * kS128SlabFloats);
+}
+
+// The four 16 x 16 blocks of one 16-row block row of a wave's 64 x 64, rounded to bf16 and stored.  B was the MFMA's
+// first operand, so lane (fr, fq) holds, per block, row fr and the four columns 4 fq .. 4 fq + 3.  Neighbouring
+// 16-lane rows of two adjacent blocks swap halves (v_permlane16_swap), after which every lane holds eight consecutive
+// columns of one block: 16-byte stores, each behind its bounds test.  `row` is the lane's row, `col0` the column of
+// its eight in the first pair of blocks.
+__device__ __forceinline__ void s128_store_blocks(const f32x4 (&acc)[4], __bf16* __restrict__ C, int M, int N, int ldc, int row, int col0) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int nb = 0; nb < 4; nb += 2) {
+    const u32x2 x = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[nb], bf16x4));
+    const u32x2 y = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[nb + 1], bf16x4));
+    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+    const u32x4 o = u32x4{r0.x, r1.x, r0.y, r1.y};
+    const int col = col0 + nb * 16;
+    if (row < M && col < N) __builtin_nontemporal_store(o, (u32x4*)(C + (size_t)row * ldc + col));  // N is a multiple of 8
+  }
+}
+
+template <int DT, int NSTAGE = kS128Stages, bool SPLIT = false>
 __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args args) {
-  const int region = (int)blockIdx.x >= args.tiles0 ? 1 : 0;  // workgroup-uniform
+  const int region = !SPLIT && (int)blockIdx.x >= args.tiles0 ? 1 : 0;  // workgroup-uniform
   const char* __restrict__ A = args.r[region].a;
   const char* __restrict__ B = args.r[region].b;
   __bf16* __restrict__ C = args.r[region].c;
@@ -1846,14 +1880,17 @@ __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args arg
 
   // XCD-aware tile assignment (bijective for any grid size), tiles walked in groups that share operand panels in L2.
   const int tiles_m = (M + kS128 - 1) / kS128, tiles_n = (N + kS128 - 1) / kS128;
-  const int nwg = region ? (int)gridDim.x - args.tiles0 : args.tiles0, bid = (int)blockIdx.x - (region ? args.tiles0 : 0);
+  const int split = SPLIT ? (int)blockIdx.x / args.tiles0 : 0;
+  const int nwg = region ? (int)gridDim.x - args.tiles0 : args.tiles0;
+  const int bid = SPLIT ? (int)blockIdx.x % args.tiles0 : (int)blockIdx.x - (region ? args.tiles0 : 0);
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   int tm, tn;
   tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
   const int rows_a = min(M - tm * kS128, kS128), rows_b = min(N - tn * kS128, kS128);
-  const char* gA = A + (size_t)tm * kS128 * row_bytes;
-  const char* gB = B + (size_t)tn * kS128 * row_bytes;
+  const int kt0 = SPLIT ? split * args.kt_per_split : 0;  // this workgroup's first K-tile
+  const char* gA = A + (size_t)tm * kS128 * row_bytes + (size_t)kt0 * BKB;
+  const char* gB = B + (size_t)tn * kS128 * row_bytes + (size_t)kt0 * BKB;
 
   // Staging: 16 pieces of 8 rows per operand tile; wave w issues pieces 4w..4w+3 of A and of B.  Lane i of a piece
   // lands at piece_base + 16 i and fetches row i >> 3, source chunk (i & 7) ^ f(i >> 3).
@@ -1897,7 +1934,7 @@ __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args arg
     b_off[h] = lds_off<DT>(wc * 64 + fr, 4 * h + fq);
   }
 
-  const int nt = (int)(row_bytes / BKB);
+  const int nt = SPLIT ? min(args.kt_per_split, (int)(row_bytes / BKB) - kt0) : (int)(row_bytes / BKB);
   // The fragments of a whole K-tile: eight 16-byte reads per operand (four 16-row blocks x two 64-byte halves).
   struct Frags {
     i32x4 a[4][2], b[4][2];
@@ -2001,29 +2038,44 @@ __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args arg
   }
   if (t < nt) ktile(Tail{}, t, f0, f1);
 
-  // Epilogue: B was the MFMA's first operand, so lane (fr, fq) holds, per 16 x 16 block, row fr and the four columns
-  // 4 fq .. 4 fq + 3.  Neighbouring 16-lane rows of two adjacent blocks swap halves (v_permlane16_swap), after which
-  // every lane holds eight consecutive columns of one block: 16-byte stores, each behind its bounds test.
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  if constexpr (SPLIT) {  // the sums over this workgroup's K-tiles, as they are
+    f32x4* const slab = s128_slab(args.work, split, args.tiles0, tm * tiles_n + tn, wave);
+#pragma unroll
+    for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+      for (int nb = 0; nb < 4; nb++) slab[(mb * 4 + nb) * 64 + lane] = acc[mb][nb];
+    return;
+  }
   const int row0 = tm * kS128 + wr * 64 + fr;
   const int col0 = tn * kS128 + wc * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
 #pragma unroll
-  for (int mb = 0; mb < 4; mb++)
+  for (int mb = 0; mb < 4; mb++) s128_store_blocks(acc[mb], C, M, N, ldc, row0 + mb * 16, col0);
+}
+
+// Second half of a GEMM split along K: workgroup (tile, w) adds up, for wave w of the tile, the accumulators that the
+// `splits` workgroups of the tile left in the workspace, always in the order of the splits (the result does not
+// depend on which workgroup finished first), and stores the tile's quarter as the unsplit kernel would.  Wave v of
+// the workgroup takes block row v.
+__global__ __launch_bounds__(kS128Threads) void gemm_s128_reduce_kernel(const float* __restrict__ work, int splits, int tiles, __bf16* __restrict__ C,
+                                                                        int M, int N, int ldc) {
+  const int lane = threadIdx.x & 63, mb = threadIdx.x >> 6;
+  const int tile = (int)blockIdx.x >> 2, wave = (int)blockIdx.x & 3;
+  const int tiles_n = (N + kS128 - 1) / kS128;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; nb += 2) {
-      const u32x2 x = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb], bf16x4));
-      const u32x2 y = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[mb][nb + 1], bf16x4));
-      const u32x2 r0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
-      const u32x2 r1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
-      const u32x4 o = u32x4{r0.x, r1.x, r0.y, r1.y};
-      const int row = row0 + mb * 16, col = col0 + nb * 16;
-      if (row < M && col < N) __builtin_nontemporal_store(o, (u32x4*)(C + (size_t)row * ldc + col));  // N is a multiple of 8
-    }
+  for (int nb = 0; nb < 4; nb++) acc[nb] = s128_slab((float*)work, 0, tiles, tile, wave)[(mb * 4 + nb) * 64 + lane];
+  for (int s = 1; s < splits; s++) {
+    const f32x4* slab = s128_slab((float*)work, s, tiles, tile, wave);
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) acc[nb] += slab[(mb * 4 + nb) * 64 + lane];
+  }
+  s128_store_blocks(acc, C, M, N, ldc, tm * kS128 + wr * 64 + fr + mb * 16, tn * kS128 + wc * 64 + (fq & 1) * 16 + (fq >> 1) * 8);
 }
 
 constexpr int kVariantUnset = -2;
-constexpr int kVariantMax = 8;
+constexpr int kVariantMax = 9;
 int g_gemm_variant = kVariantUnset;
 
 int gemm_variant() {
@@ -2079,6 +2131,50 @@ int launch_lds(gemm_fn_t kfn, int grid, int threads, int lds_bytes, const GemmAr
   return GMD_OK;
 }
 
+// Split along K for problems of few small tiles and a long K (1024 x 1024 x 4096: 64 tiles of 128 x 128 on 256 CUs,
+// each walking 64 K-tiles): `splits` workgroups per tile, each over a range of K-tiles, and a second kernel that adds
+// their accumulators up in a fixed order.  The sums differ from the unsplit order in the last bits, but not from launch
+// to launch.  What it costs: 64 KiB of fp32 per workgroup written and read once, and the second launch.
+constexpr int kSplitMaxSlabs = 256;       // tiles x splits, one slab of four wave slabs each
+constexpr int kSplitMax = 8;
+constexpr int kSplitMinKtiles = 32;       // automatic choice: K-tiles of the whole problem ...
+constexpr int kSplitMinKtilesEach = 8;    // ... and of every split (the prologue alone is four)
+int split_k_count(int tiles, int ktiles, bool asked) {
+  const int cus = persistent_grid();
+  if (tiles <= 0 || tiles * 2 > cus || tiles * 2 > kSplitMaxSlabs) return 1;
+  if (!asked && ktiles < kSplitMinKtiles) return 1;
+  // (asked for, a short K is split down to single K-tiles; from 16 K-tiles on the count is the automatic one)
+  const int each = asked && ktiles < 2 * kSplitMinKtilesEach ? 1 : kSplitMinKtilesEach;
+  int s = std::min(std::min(cus, kSplitMaxSlabs) / tiles, std::min(kSplitMax, ktiles / each));
+  if (s < 2) return 1;
+  const int per = (ktiles + s - 1) / s;
+  return (ktiles + per - 1) / per;  // no split without a K-tile
+}
+
+// The workspace of the split: one per device and stream (launches on one stream follow one another; two streams may
+// run two split GEMMs at once), allocated at first use and kept for the life of the process.
+float* split_workspace(hipStream_t st) {
+  struct Ws {
+    int dev;
+    hipStream_t st;
+    float* p;
+  };
+  static std::mutex mu;
+  static std::vector<Ws> all;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Ws& w : all)
+    if (w.dev == dev && w.st == st) return w.p;
+  float* p = nullptr;
+  if (hipMalloc((void**)&p, (size_t)kSplitMaxSlabs * 4 * kS128SlabFloats * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    p = nullptr;  // remembered: the caller runs unsplit, now and later
+  }
+  all.push_back(Ws{dev, st, p});
+  return p;
+}
+
 constexpr int kScaleRingBytes = 4 * 8 * 256;  // gemm_w4_kernel, MX-fp8: four waves x eight slots x one unit
 
 template <int DT>
@@ -2097,7 +2193,7 @@ int launch_gemm_t(const GemmArgs& g) {
   // (0, 1, 3, 4, 5 and 7) all stay on the K=32 one, for every shape.
   constexpr bool kFp8 = DT == GMD_DT_FP8;
   const int asked = gemm_variant();
-  const bool fp8_wide = kFp8 && (asked < 0 || asked > kVariantMax || asked == 2 || asked == 6 || asked == 8);
+  const bool fp8_wide = kFp8 && (asked < 0 || asked > kVariantMax || asked == 2 || asked == 6 || asked == 8 || asked == 9);
   // Small problems and ragged edges (bf16 and unscaled fp8; MX-fp8 has no small-tile kernel).
   // * Where the 256 x 256 tiles leave CUs idle, 128 x 128 tiles (schedule 8) fill them: taken when every CU gets at
   //   most one small tile (2048^3: 64 large tiles on 256 CUs, or 256 small ones).  With several small tiles per CU the
@@ -2118,6 +2214,7 @@ int launch_gemm_t(const GemmArgs& g) {
       a.tiles0 = tiles128(r0.m, r0.n);
       a.ldc = ldc;
       a.row_bytes = g.row_bytes;
+      a.work = nullptr, a.kt_per_split = 0;
       const int grid_s = a.tiles0 + (r1.m > 0 && r1.n > 0 ? tiles128(r1.m, r1.n) : 0);
       thread_local int attr_dev = -1;
       int dev = 0;
@@ -2132,7 +2229,33 @@ int launch_gemm_t(const GemmArgs& g) {
     };
     const S128Region whole_matrix{(const char*)g.a, (const char*)g.b, (__bf16*)g.c, g.m, g.n}, none{nullptr, nullptr, nullptr, 0, 0};
     const bool automatic = asked < 0 || asked > kVariantMax;
-    if (asked == 8 || (automatic && tiles128(g.m, g.n) <= cus)) return small(whole_matrix, none);
+    if (asked == 9 || (automatic && tiles128(g.m, g.n) <= cus)) {
+      const int tiles = tiles128(g.m, g.n), splits = split_k_count(tiles, (int)ktiles, asked == 9);
+      float* const work = splits > 1 ? split_workspace(g.st) : nullptr;
+      if (work) {
+        S128Args a;
+        a.r[0] = whole_matrix, a.r[1] = none;
+        a.tiles0 = tiles;
+        a.ldc = ldc;
+        a.row_bytes = g.row_bytes;
+        a.work = work;
+        a.kt_per_split = ((int)ktiles + splits - 1) / splits;
+        thread_local int attr_dev = -1;
+        int dev = 0;
+        GMD_HIP(hipGetDevice(&dev));
+        if (attr_dev != dev) {
+          GMD_HIP(hipFuncSetAttribute((const void*)gemm_s128_kernel<DT, kS128Stages, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kS128LdsBytes));
+          attr_dev = dev;
+        }
+        gemm_s128_kernel<DT, kS128Stages, true><<<tiles * splits, kS128Threads, kS128LdsBytes, g.st>>>(a);
+        GMD_HIP(hipGetLastError());
+        gemm_s128_reduce_kernel<<<tiles * 4, kS128Threads, 0, g.st>>>(work, splits, tiles, (__bf16*)g.c, g.m, g.n, ldc);
+        GMD_HIP(hipGetLastError());
+        return GMD_OK;
+      }
+    }
+    if (asked == 8 || asked == 9 || (automatic && tiles128(g.m, g.n) <= cus)) return small(whole_matrix, none);
     const int m_main = g.m / BM * BM, n_main = g.n / BN * BN;
     if (automatic && !g.ldc && m_main > 0 && n_main > 0 && (m_main < g.m || n_main < g.n)) {
       auto rounds = [&](int tiles) { return (double)((tiles + cus - 1) / cus); };
@@ -2221,7 +2344,7 @@ int launch_gemm_t(const GemmArgs& g) {
   // the only pipeline that carries MX scales, and since its epilogue stores whole rows from neighbouring lanes it is
   // ahead of the eight-wave kernels on bf16 and fp8 at 4096 (4-6 %), 8192 (0.5-1.6 %) and 16384 (0.6-1.1 %) alike.
   int variant = gemm_variant();
-  if (variant < 0 || variant >= kVariantMax) variant = 2;
+  if (variant < 0 || variant >= 8) variant = 2;
   if (kMx && variant != 0 && variant != 6) variant = 2;
   if (!pairs) variant = 0;
   if (variant == 3 && !stream_ok) variant = 1;
@@ -2261,6 +2384,17 @@ int gmd_gemm_set_variant(int variant) {
   if (variant < -1 || variant > kVariantMax) return GMD_ERR_BADPARAM;
   g_gemm_variant = variant;
   return GMD_OK;
+}
+
+// Into how many ranges of K the schedule in force splits a GEMM of this shape (1: not at all).
+int gmd_gemm_split_k(int dtype, int m, int n, int k) {
+  if ((dtype != GMD_DT_BF16 && dtype != GMD_DT_FP8) || m <= 0 || n <= 0 || k <= 0) return 1;
+  const int asked = gemm_variant();
+  const bool automatic = asked < 0 || asked > kVariantMax;
+  if (!automatic && asked != 9) return 1;
+  const int tiles = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
+  if (automatic && tiles > persistent_grid()) return 1;
+  return split_k_count(tiles, (int)((size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB), asked == 9);
 }
 
 // Ablation builds only: per-workgroup (shader ticks, 100 MHz ticks) pairs of the last stamped launch.

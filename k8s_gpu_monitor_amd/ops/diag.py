@@ -208,10 +208,17 @@ def gemm_set_variant(variant):
     1 = eight waves x 128x64 per tile, 2 = four waves x 128x128 (accumulators in AGPRs), 3 = eight waves x 128x64
     as one stream per CU over its tiles, 4 / 5 = schedule 1 with the narrow / cached epilogue, 6 = schedule 2 as one
     stream per CU (A/B reference; slower than 2, see docs/diagnostics.md), 7 = schedule 2 on the K=32 fp8 instruction
-    (unscaled fp8 runs -1, 2 and 6 on the K=128 instruction, at twice the rate, and the others on the K=32 one)."""
+    (unscaled fp8 runs -1, 2 and 6 on the K=128 instruction, at twice the rate, and the others on the K=32 one),
+    8 = 128 x 128 tiles, 9 = 128 x 128 tiles split along K where they fill at most half of the CUs (see gemm_split_k)."""
     rc = _lib().gmd_gemm_set_variant(int(variant))
     if rc:
         raise DiagError(rc, "gmd_gemm_set_variant")
+
+
+def gemm_split_k(dtype, m, n, k):
+    """Number of K ranges the schedule in force splits a GEMM of this shape into on the current device (1 = no split).
+    A split GEMM adds its products up in another order than the unsplit schedules, the same one at every launch."""
+    return int(_lib().gmd_gemm_split_k(DTYPES[dtype], int(m), int(n), int(k)))
 
 
 COLLECTIVES = {"all_reduce": 0, "all_gather": 1, "reduce_scatter": 2, "all_to_all": 3, "broadcast": 4}

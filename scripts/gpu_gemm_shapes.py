@@ -33,7 +33,7 @@ def timed(fn, n=30):
 
 for dtype in ("bf16", "fp8"):
     kt = 64 if dtype == "bf16" else 128
-    for (m, n, k) in [(1024, 1024, 4096), (2048, 2048, 2048), (2048, 2048, 8192), (3072, 3072, 3072), (2048, 4096, 4096), (4096, 4096, 4096), (8192, 8192, 8192), (16384, 16384, 16384), (8192, 8192, 8192 + kt), (8200, 8200, 8192), (8000, 8000, 8192), (4000, 4104, 4096 + kt),
+    for (m, n, k) in [(512, 512, 8192), (1024, 1024, 2048), (1024, 1024, 4096), (1024, 1024, 16384), (1024, 2048, 8192), (2048, 2048, 2048), (2048, 2048, 8192), (3072, 3072, 3072), (2048, 4096, 4096), (4096, 4096, 4096), (8192, 8192, 8192), (16384, 16384, 16384), (8192, 8192, 8192 + kt), (8200, 8200, 8192), (8000, 8000, 8192), (4000, 4104, 4096 + kt),
                       (1000, 520, 5 * kt)]:
         a = torch.randn(m, k, device=dev)
         b = torch.randn(n, k, device=dev)
@@ -41,6 +41,8 @@ for dtype in ("bf16", "fp8"):
         c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
         ms = timed(lambda: diag.gemm_launch(dtype, a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, stream))
         row = {"dtype": dtype, "m": m, "n": n, "k": k, "ms": round(ms, 4), "tflops": round(2.0 * m * n * k / ms / 1e9, 1)}
+        if diag.gemm_split_k(dtype, m, n, k) > 1:
+            row["split_k"] = diag.gemm_split_k(dtype, m, n, k)
         # the two tile sizes the default chooses between: 256 x 256 (schedule 2) and 128 x 128 (schedule 8)
         for name, variant in (("large", 2), ("small", 8)):
             if variant == 8 and m * n > 8192 * 8192:

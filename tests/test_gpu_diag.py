@@ -291,13 +291,15 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
                           (4352, 4352, 4 * kt), (4352, 4608, 10 * kt)]:  # 289 / 306 tiles: more than CUs, variant 3 streams
             G = _Gemm(diag, dev, m, n, k, dtype, seed=k)
             outs = {}
-            for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, -1):
+            splits = {}
+            for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, -1):
                 diag.gemm_set_variant(variant)
+                splits[variant] = diag.gemm_split_k(dtype, m, n, k)
                 c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
                 G.launch(c)
                 torch.cuda.synchronize()
                 outs[variant] = c
-                if variant in (1, 2, 3, 6, 7, 8):  # 4 and 5 differ from 1 in the epilogue only
+                if variant in (1, 2, 3, 6, 7, 8, 9):  # 4 and 5 differ from 1 in the epilogue only
                     c2 = torch.empty_like(c)
                     for _ in range(20):
                         G.launch(c2)
@@ -305,8 +307,18 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
                     assert torch.equal(c2, c), (variant, m, n, k)
             # Unscaled fp8: the default, 2 and 6 run on the K=128 instruction, which adds the same products up in another
             # order; 7 is schedule 2 on the K=32 instruction.  Each group is identical within itself.
-            wide = (2, 6, 8, -1) if dtype == "fp8" else ()
-            for variant in (1, 2, 3, 4, 5, 6, 7, -1) + (() if dtype == "mxfp8" else (8,)):
+            # A GEMM split along K (9, and the default for few tiles and many K-tiles: 512 x 512 x 32 K-tiles in 4,
+            # 1024 x 768 x 128 in 5) adds up in an order of its own: the same for every launch and for the same number of
+            # splits, and as close to fp32 as the others.
+            wide = (2, 6, 8, 9, -1) if dtype == "fp8" else ()
+            assert all(splits[v] == 1 for v in range(9)) and (dtype != "mxfp8" or splits[9] == splits[-1] == 1)
+            assert splits[-1] == ({(512, 512, 32 * kt): 4, (1024, 768, 128 * kt): 5}.get((m, n, k), 1) if dtype != "mxfp8" else 1)
+            for variant in (1, 2, 3, 4, 5, 6, 7, -1) + (() if dtype == "mxfp8" else (8, 9)):
+                if splits[variant] > 1:
+                    ref = G.ref()
+                    assert ((outs[variant].float() - ref).abs().max() / ref.abs().max()).item() < 6e-3, (variant, m, n, k)
+                    assert splits[variant] != splits[9] or torch.equal(outs[variant], outs[9]), (variant, m, n, k)
+                    continue
                 assert torch.equal(outs[2 if variant in wide else 0], outs[variant]), (variant, m, n, k)
             if wide:
                 ref = G.ref()
@@ -360,6 +372,47 @@ def test_gemm_takes_the_operators_shape(diag, dev, dtype, shape):
                 assert torch.equal(c2, c), variant
     finally:
         diag.gemm_set_variant(-1)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_gemm_split_along_k(diag, dev, dtype):
+    """Few tiles and a long K: the default gives every tile to several workgroups, each over a range of K-tiles, and adds
+    their fp32 sums up in a second kernel.  Ragged shapes (rows and columns beyond the matrix, a last range shorter than
+    the others), a guard band behind C, the same bits at every launch, and two streams at once (each has a workspace of
+    its own, so neither reads the other's partial sums)."""
+    kt = 64 if dtype == "bf16" else 128
+    for (m, n, ktiles, want) in [(1024, 1024, 64, 4), (1000, 520, 40, 5), (128, 128, 100, 8), (1024, 2048, 33, 2), (2048, 2048, 64, 1)]:
+        k = ktiles * kt
+        assert diag.gemm_split_k(dtype, m, n, k) == want, (m, n, k)
+        G = _Gemm(diag, dev, m, n, k, dtype, seed=m + k)
+        guard = 4096
+        buf = torch.full((m * n + guard,), 7.0, dtype=torch.bfloat16, device=dev)
+        c = buf[:m * n].view(m, n)
+        G.launch(c)
+        torch.cuda.synchronize()
+        ref = G.ref()
+        err = (c.float() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 6e-3, (m, n, k, err)
+        assert (buf[m * n:] == 7.0).all()
+        c2 = torch.empty_like(c)
+        for _ in range(20):
+            G.launch(c2)
+        torch.cuda.synchronize()
+        assert torch.equal(c2, c), (m, n, k)
+    # two streams, different operands, launches interleaved
+    m, n, k = 1024, 1024, 64 * kt
+    G1, G2 = _Gemm(diag, dev, m, n, k, dtype, seed=1), _Gemm(diag, dev, m, n, k, dtype, seed=2)
+    want1, want2 = torch.empty(m, n, dtype=torch.bfloat16, device=dev), torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+    G1.launch(want1)
+    G2.launch(want2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    got1, got2 = torch.empty_like(want1), torch.empty_like(want2)
+    for _ in range(50):
+        for G, st, got in ((G1, s1, got1), (G2, s2, got2)):
+            diag.gemm_launch(dtype, G.a.data_ptr(), G.b.data_ptr(), got.data_ptr(), m, n, k, st.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(got1, want1) and torch.equal(got2, want2)
 
 
 def test_mx_gemm_takes_an_odd_number_of_k_tiles(diag, dev):
