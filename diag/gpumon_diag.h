@@ -202,15 +202,21 @@ GMD_API int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int r
  * 7 = schedule 2 on the K=32 instruction for unscaled fp8 (2 for the other data types).
  * 8 = 128 x 128 tiles, four waves of 64 x 64, two workgroups per CU (bf16 and fp8, any M, N in multiples of 8): what
  * the default picks where the 256 x 256 tiles cannot fill the chip (2048^3 is 64 of them on 256 CUs); MX-fp8 runs 2.
- * 9 = schedule 8 split along K: where the small tiles fill at most half of the CUs, several workgroups share a tile, each
- * over a range of K-tiles, and a second kernel adds their fp32 sums up in a fixed order (the default takes it from
- * 32 K-tiles on, 1024 x 1024 x 4096; asked for, it splits whatever has two K-tiles; otherwise 8 runs).
- * All schedules but 9 give
+ * 9 = schedule 8 split along K: several workgroups share a tile, each over a range of K-tiles, and a second kernel adds
+ * their fp32 sums up in a fixed order; 10 = the same on the 256 x 256 tiles of schedule 2 (whole tiles, K-tiles in pairs).
+ * Asked for, they split into as many ranges as fit (at most 8 and one workgroup per CU), or into gmd_gemm_set_split()
+ * ranges; where a shape cannot be split, 8 and 2 run.  The default takes one of them where a model of the launch times
+ * has it ahead (few tiles and a long K: 1024 x 1024 x 4096, 2048 x 2048 x 8192); gmd_gemm_plan() says what a shape gets.
+ * All schedules but 9 and 10 give
  * bit-identical results, except that unscaled fp8 has two groups of them, one per MFMA instruction (K=128: -1, 2, 6, 8;
  * K=32: the others), whose sums differ in the order of their additions; a split GEMM adds the same products in
  * another order again, the same one at every launch.  Also settable with the environment variable GMD_GEMM_VARIANT before the first launch. */
 GMD_API int gmd_gemm_set_variant(int variant);
-/* Number of K ranges into which the schedule in force splits a GEMM of this shape on the current device (1 = no split). */
+/* What the schedule in force does with a GEMM of this shape on the current device: *schedule = 9 or 10 and *splits = the
+ * number of K ranges, or 0 and 1 (not split).  gmd_gemm_split_k returns the number of ranges alone. */
+GMD_API int gmd_gemm_plan(int dtype, int m, int n, int k, int* schedule, int* splits);
+/* Number of K ranges schedules 9 and 10 use when asked for: 2..8, or 0 for as many as fit (the default). */
+GMD_API int gmd_gemm_set_split(int splits);
 GMD_API int gmd_gemm_split_k(int dtype, int m, int n, int k);
 
 /* Timing-only ablation builds (make diag-ablate): per-workgroup pairs (shader-clock ticks,

@@ -241,6 +241,62 @@ __device__ __forceinline__ void store_acc_rows_edge(const f32x4 (&acc)[8][8], __
   }
 }
 
+// Which range of K and which tile a workgroup of a split GEMM takes (grid = tiles x splits).  The dispatcher deals
+// workgroups to the eight XCDs in turn.  Where the numbers divide, an XCD gets ONE range of K and a run of consecutive
+// tiles of the grouped walk (for 64 tiles in 4 ranges: XCD x takes range x % 4 of tiles 32 (x / 4) ...), so that its 32
+// workgroups share operand panels in its L2; with every range of a tile on the same XCD an XCD would fetch `splits`
+// times as many panels per step (2048 x 2048 x 16384 in 4: 105 -> 75 us).  *tile is then the walk's index itself (true),
+// otherwise the block id to be spread over the XCDs as in an unsplit launch (false).  Short ranges (under 32 K-tiles,
+// 4 KiB of a row) stay with that: an XCD that reads one short window of every operand row was measured slower
+// (1024 x 1024 x 4096 in 4 ranges of 16: 19.5 -> 21.0 us; ranges of 32 and more: level or ahead, 33.4 -> 29.7 us at
+// 1024 x 512 x 16384 in 8).
+__device__ __forceinline__ bool split_of_block(int block, int splits, int tiles, int per, int* split, int* tile) {
+  const int groups = splits <= 8 ? 8 / splits : 0;  // XCDs per range of K
+  if (per >= 32 && groups * splits == 8 && tiles % groups == 0) {
+    const int x = block & 7, per_xcd = tiles / groups;
+    *split = x % splits;
+    *tile = (x / splits) * per_xcd + (block >> 3);
+    return true;
+  }
+  *split = block / tiles;
+  *tile = block % tiles;
+  return false;
+}
+
+// A GEMM of 256 x 256 tiles split along K (gemm_w4_kernel with EPI = 4): a wave's 128 x 128 accumulators in the
+// workspace, one 16-byte word per lane and 16 x 16 block (mb * 8 + nb), so that a wave's store or load of a block is one
+// contiguous KiB.  gemm_w4_reduce_kernel: workgroup (tile, wave, half), wave v of it adds up block row mb = 4 half + v of
+// that wave's accumulators over the ranges, always in the order of the ranges, and stores it as store_acc_rows does.
+constexpr size_t kW4SlabFloats = 64 * 64 * 4;  // per wave
+__device__ __forceinline__ f32x4* w4_slab(float* work, int split, int tiles, int tile, int wave) {
+  return (f32x4*)(work + (((size_t)split * tiles + tile) * 4 + wave) * kW4SlabFloats);
+}
+__global__ __launch_bounds__(256) void gemm_w4_reduce_kernel(const float* __restrict__ work, int splits, int tiles, int tiles_n,
+                                                             __bf16* __restrict__ C, size_t ldc) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+  const int tile = (int)blockIdx.x >> 3, wave = ((int)blockIdx.x >> 1) & 3, mb = ((int)blockIdx.x & 1) * 4 + (int)(threadIdx.x >> 6);
+  const int tm = tile / tiles_n, tn = tile % tiles_n, wr = wave >> 1, wc = wave & 1;
+  f32x4 acc[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; nb++) acc[nb] = w4_slab((float*)work, 0, tiles, tile, wave)[(mb * 8 + nb) * 64 + lane];
+  for (int s = 1; s < splits; s++) {
+    const f32x4* slab = w4_slab((float*)work, s, tiles, tile, wave);
+#pragma unroll
+    for (int nb = 0; nb < 8; nb++) acc[nb] += slab[(mb * 8 + nb) * 64 + lane];
+  }
+  __bf16* const base = C + (size_t)(tm * BM + wr * 128 + fq * 32) * ldc + tn * BN + wc * 128 + fr * 8;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    u32x4 o;
+#pragma unroll
+    for (int h = 0; h < 4; h++) o[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{acc[2 * h][r], acc[2 * h + 1][r]}, bf16x2));
+    __builtin_nontemporal_store(o, (u32x4*)(base + (size_t)(r * 8 + mb) * ldc));
+  }
+}
+
 // What the LDS-DMA of a K-tile beyond the last one reads when the K-tile count is odd (the pipelines walk K-tiles in
 // pairs): zeros for both operands, so that the pair's second half adds nothing.
 __device__ uint4 g_gemm_zero_slab[264];  // 4 KiB + 128 B: the odd K-tile of a pair is read 128 bytes further on
@@ -1035,20 +1091,30 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // Per-tile launch: workgroup = tile.  Stream: XCD x owns a contiguous chunk of tiles, its workgroup j walks tiles
   // j, j + G/8, ... of the chunk.
   static_assert(!(GEN && STREAM), "the stream walks full tiles and even K-tile counts only");
+  // EPI = 4: the GEMM is split along K.  The grid is `tiles` workgroups per range of K-tiles; workgroup b walks `ldc`
+  // K-tiles (the last range what is left) of tile b % tiles from K-tile (b / tiles) * ldc on and leaves its fp32
+  // accumulators, as they are, in the workspace that C points to (gemm_w4_reduce_kernel adds the ranges up and stores C).
+  constexpr bool kSplit = EPI == 4;
+  static_assert(!kSplit || (!STREAM && !GEN && !kScaled && ABL == 0), "the split runs whole tiles of bf16 or unscaled fp8");
   const int tiles_m = GEN ? (M + BM - 1) / BM : M / BM, tiles_n = GEN ? (N + BN - 1) / BN : N / BN;
-  const int nunits = STREAM ? tiles_m * tiles_n : (int)gridDim.x;
-  const int xcd = blockIdx.x & 7, q8 = nunits >> 3, r8n = nunits & 7;
+  const int nunits = STREAM || kSplit ? tiles_m * tiles_n : (int)gridDim.x;
+  int bid = (int)blockIdx.x, split = 0;
+  bool split_by_xcd = false;
+  if constexpr (kSplit) split_by_xcd = split_of_block((int)blockIdx.x, (int)gridDim.x / nunits, nunits, ldc, &split, &bid);
+  const int kt_first = kSplit ? split * ldc : 0;
+  const int kcount = kSplit ? min(ldc, (int)(row_bytes / BKB) - kt_first) : (int)(row_bytes / BKB);  // K-tiles this workgroup walks
+  const int xcd = bid & 7, q8 = nunits >> 3, r8n = nunits & 7;
   const int chunk0 = xcd < r8n ? xcd * (q8 + 1) : r8n * (q8 + 1) + (xcd - r8n) * q8;
   const int chunk_end = chunk0 + q8 + (xcd < r8n ? 1 : 0);
   const int tile_step = STREAM ? max((int)gridDim.x >> 3, 1) : 1;
-  int wgid = chunk0 + (int)(blockIdx.x >> 3);
+  int wgid = split_by_xcd ? bid : chunk0 + (bid >> 3);
   if (STREAM && wgid >= chunk_end) return;  // whole workgroup, before any barrier
   int tm, tn;
   tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
   // Tile bases carry the offset bias of the DMA lanes (see off_imm) from the start, so that no phase has to subtract it.
   constexpr int kOffBias = 3 * 1024;
-  const char* gA = A + (size_t)tm * BM * row_bytes - kOffBias;
-  const char* gB = B + (size_t)tn * BN * row_bytes - kOffBias;
+  const char* gA = A + (size_t)tm * BM * row_bytes - kOffBias + (size_t)kt_first * BKB;
+  const char* gB = B + (size_t)tn * BN * row_bytes - kOffBias + (size_t)kt_first * BKB;
   // the tile after this one (stream only): where the last pair's surplus half-tiles come from
   bool has_next = false;
   int ntm = tm, ntn = tn;
@@ -1244,7 +1310,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   };
   // What the DMA of one pair of K-tiles needs, worked out once per pair (fetch_pair): the four bases at the pair's even
   // K-tile, whether its odd K-tile is the zero one (GEN, odd count), and the MX scale tensors and K-tile index.
-  const int last_kt = (int)(row_bytes / BKB) - 1;
+  const int last_kt = kcount - 1;
   const char* pair_base[4];
   bool pair_zero_odd = false;
   const uint32_t* pair_sa = sc_a;
@@ -1444,7 +1510,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     }
   };
 
-  const int npairs = ((int)(row_bytes / BKB) + (GEN ? 1 : 0)) >> 1;
+  const int npairs = (kcount + (GEN ? 1 : 0)) >> 1;
   // The launcher sends no shape with fewer than one pair.  Saying so removes the path round the K loop, on which the
   // accumulators are constants, and with it the copies that merge the two paths at the top of the block behind the loop:
   // those read accumulator registers ahead of the drain.
@@ -1527,7 +1593,13 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
     // that live through the K loop for nothing, and that the register allocator may decide to spill and reload here.
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
-    if constexpr (kRowsDealt && GEN) store_acc_rows_edge<EPI>(acc, C, (size_t)ldc, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e, M, N);
+    if constexpr (kSplit) {
+      f32x4* const slab = w4_slab((float*)C, split, nunits, tm * tiles_n + tn, wave);
+#pragma unroll
+      for (int mb = 0; mb < 8; mb++)
+#pragma unroll
+        for (int nb = 0; nb < 8; nb++) slab[(mb * 8 + nb) * 64 + lane_e] = acc[mb][nb];
+    } else if constexpr (kRowsDealt && GEN) store_acc_rows_edge<EPI>(acc, C, (size_t)ldc, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e, M, N);
     else if constexpr (kRowsDealt) store_acc_rows<EPI>(acc, C, (size_t)ldc, tm * BM + wr * 128, tn * BN + wc * 128, fr_e, fq_e);
     else store_acc<8, EPI>(acc, C, (size_t)ldc, tm * BM + wr * 128 + fr, tn * BN + wc * 128, fq);
   }
@@ -1811,7 +1883,7 @@ double peak_flops_per_mfma(int dt) {
 // no kernel for large problems; the dispatcher uses it where the large tiles cannot fill the chip.
 // Any M, any N that is a multiple of 8, whole K-tiles: rows beyond the matrix are fetched from its last row and
 // their results are not stored.  The SPLIT instantiation walks a range of the K-tiles and leaves its accumulators in a
-// workspace instead of storing C (split_k_count() below says when).
+// workspace instead of storing C (plan_split() below says when).
 constexpr int kS128 = 128;
 constexpr int kS128Threads = 256;
 constexpr int kS128TileBytes = kS128 * BKB;  // 16 KiB per operand per stage
@@ -1880,11 +1952,12 @@ __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args arg
 
   // XCD-aware tile assignment (bijective for any grid size), tiles walked in groups that share operand panels in L2.
   const int tiles_m = (M + kS128 - 1) / kS128, tiles_n = (N + kS128 - 1) / kS128;
-  const int split = SPLIT ? (int)blockIdx.x / args.tiles0 : 0;
   const int nwg = region ? (int)gridDim.x - args.tiles0 : args.tiles0;
-  const int bid = SPLIT ? (int)blockIdx.x % args.tiles0 : (int)blockIdx.x - (region ? args.tiles0 : 0);
+  int split = 0, bid = (int)blockIdx.x - (region ? args.tiles0 : 0);
+  bool split_by_xcd = false;
+  if constexpr (SPLIT) split_by_xcd = split_of_block((int)blockIdx.x, (int)gridDim.x / args.tiles0, args.tiles0, args.kt_per_split, &split, &bid);
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int wgid = split_by_xcd ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   int tm, tn;
   tile_of(wgid, tiles_m, tiles_n, &tm, &tn);
   const int rows_a = min(M - tm * kS128, kS128), rows_b = min(N - tn * kS128, kS128);
@@ -2075,7 +2148,7 @@ __global__ __launch_bounds__(kS128Threads) void gemm_s128_reduce_kernel(const fl
 }
 
 constexpr int kVariantUnset = -2;
-constexpr int kVariantMax = 9;
+constexpr int kVariantMax = 10;
 int g_gemm_variant = kVariantUnset;
 
 int gemm_variant() {
@@ -2131,24 +2204,82 @@ int launch_lds(gemm_fn_t kfn, int grid, int threads, int lds_bytes, const GemmAr
   return GMD_OK;
 }
 
-// Split along K for problems of few small tiles and a long K (1024 x 1024 x 4096: 64 tiles of 128 x 128 on 256 CUs,
-// each walking 64 K-tiles): `splits` workgroups per tile, each over a range of K-tiles, and a second kernel that adds
-// their accumulators up in a fixed order.  The sums differ from the unsplit order in the last bits, but not from launch
-// to launch.  What it costs: 64 KiB of fp32 per workgroup written and read once, and the second launch.
-constexpr int kSplitMaxSlabs = 256;       // tiles x splits, one slab of four wave slabs each
+// Split along K where the tiles cannot fill the chip and K is long (1024 x 1024 x 4096 is 64 tiles of 128 x 128 on 256
+// CUs, each walking 64 K-tiles; 2048 x 2048 x 8192 is one LDS- and L2-bound small tile per CU, or 64 large tiles): several
+// workgroups per tile, each over a range of K-tiles, and a second kernel that adds their fp32 accumulators up in a fixed
+// order.  The sums differ from the unsplit order in the last bits, but not from launch to launch.
+//   schedule 9:  gemm_s128_kernel<.., SPLIT> + gemm_s128_reduce_kernel, 64 KiB of partial sums per workgroup;
+//   schedule 10: gemm_w4_kernel<.., EPI = 4> + gemm_w4_reduce_kernel, 256 KiB per workgroup, whole 256 x 256 tiles and
+//                K-tiles in pairs.  The large tile needs half the operand bytes per FLOP of the small one, which is what
+//                bounds the small-tile kernel (an XCD's L2 delivers about 70 GB/s to a CU).
+// Which of them, and into how many ranges, is decided by a model of the time each takes, in microseconds, fitted to
+// scripts/gpu_gemm_split_sweep.py (profiles/gemm_split_sweep.json; bf16 and fp8 cost the same per 128-byte K-tile):
+//   a K-tile costs a workgroup 0.475 us on small tiles and 0.9 us on large ones, more with more of the chip busy (the
+//   clock under the power cap, and the L2); a launch costs 4 to 6 us before its first and after its last K-tile; the
+//   partial sums cost 0.29 us per MiB (written, then read) and the second launch 2 to 4 us.
+// A split is taken when the model has it 3 % ahead of the unsplit launch.
+constexpr int kSplitMaxSlabs = 256;  // workgroups of a split launch (the workspace holds 256 KiB for each)
 constexpr int kSplitMax = 8;
-constexpr int kSplitMinKtiles = 32;       // automatic choice: K-tiles of the whole problem ...
-constexpr int kSplitMinKtilesEach = 8;    // ... and of every split (the prologue alone is four)
-int split_k_count(int tiles, int ktiles, bool asked) {
+struct SplitPlan {
+  int schedule;  // 0: no split; 9: small tiles; 10: large tiles
+  int splits;
+  int per;       // K-tiles per range (the last range: what is left)
+};
+int g_gemm_splits = 0;  // gmd_gemm_set_split: the number of ranges schedules 9 and 10 use when asked for; 0 = their own choice
+
+SplitPlan small_split(int tiles, int ktiles, int s) {
+  const int room = std::min(persistent_grid(), kSplitMaxSlabs);
+  if (tiles <= 0 || s < 2 || s > kSplitMax || tiles * s > room || s > ktiles) return SplitPlan{0, 1, ktiles};
+  const int per = (ktiles + s - 1) / s, eff = (ktiles + per - 1) / per;  // no range without a K-tile
+  return eff >= 2 ? SplitPlan{9, eff, per} : SplitPlan{0, 1, ktiles};
+}
+SplitPlan large_split(int m, int n, int ktiles, int s) {
+  const int room = std::min(persistent_grid(), kSplitMaxSlabs);
+  if (m % BM || n % BN || ktiles < 4 || (ktiles & 1)) return SplitPlan{0, 1, ktiles};
+  const int tiles = (m / BM) * (n / BN);
+  if (s < 2 || s > kSplitMax || tiles * s > room || 2 * s > ktiles) return SplitPlan{0, 1, ktiles};
+  const int per = ((ktiles + s - 1) / s + 1) & ~1, eff = (ktiles + per - 1) / per;  // whole pairs of K-tiles
+  return eff >= 2 ? SplitPlan{10, eff, per} : SplitPlan{0, 1, ktiles};
+}
+
+SplitPlan plan_split(int m, int n, int ktiles, int asked) {
   const int cus = persistent_grid();
-  if (tiles <= 0 || tiles * 2 > cus || tiles * 2 > kSplitMaxSlabs) return 1;
-  if (!asked && ktiles < kSplitMinKtiles) return 1;
-  // (asked for, a short K is split down to single K-tiles; from 16 K-tiles on the count is the automatic one)
-  const int each = asked && ktiles < 2 * kSplitMinKtilesEach ? 1 : kSplitMinKtilesEach;
-  int s = std::min(std::min(cus, kSplitMaxSlabs) / tiles, std::min(kSplitMax, ktiles / each));
-  if (s < 2) return 1;
-  const int per = (ktiles + s - 1) / s;
-  return (ktiles + per - 1) / per;  // no split without a K-tile
+  const int t128 = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
+  const bool whole = m % BM == 0 && n % BN == 0 && ktiles >= 2 && (ktiles & 1) == 0;
+  const int large = whole ? (m / BM) * (n / BN) : 0;
+  const SplitPlan none{0, 1, ktiles};
+  if (asked == 9 || asked == 10) {  // the largest number of ranges that fits, or the number set
+    for (int s = g_gemm_splits ? g_gemm_splits : kSplitMax; s >= 2; s--) {
+      const SplitPlan p = asked == 9 ? small_split(t128, ktiles, s) : large_split(m, n, ktiles, s);
+      if (p.schedule || g_gemm_splits) return p;
+    }
+    return none;
+  }
+  const double full = (double)cus;
+  auto busy = [&](int wgs) { return std::min(wgs, cus) / full; };
+  auto rounds = [&](int wgs) { return (double)((wgs + cus - 1) / cus); };
+  auto small_ktile = [&](int wgs) { return 0.475 * (1.0 + 0.15 * busy(wgs) * busy(wgs)); };
+  auto large_ktile = [&](int wgs) { return 0.9 + 0.35 * busy(wgs) * busy(wgs) * busy(wgs); };
+  // what runs unsplit: small tiles while every CU gets at most one, large tiles beyond (launch_gemm_t)
+  double best = t128 <= cus ? 4.0 + ktiles * small_ktile(t128) : large ? 5.5 + rounds(large) * ktiles * 0.89 : 0.0;
+  if (best == 0.0) return none;  // more small tiles than CUs and no whole large tiles: the general kernel
+  best *= 0.97;
+  SplitPlan plan = none;
+  for (int s = 2; s <= kSplitMax; s++) {
+    const SplitPlan p = small_split(t128, ktiles, s);
+    if (!p.schedule || p.per < 4) continue;
+    const int wgs = t128 * p.splits;
+    const double t = 8.0 + p.per * small_ktile(wgs) + 0.29 * wgs / 16.0;
+    if (t < best) best = t, plan = p;
+  }
+  for (int s = 2; s <= kSplitMax; s++) {
+    const SplitPlan p = large_split(m, n, ktiles, s);
+    if (!p.schedule || p.per < 16) continue;
+    const int wgs = large * p.splits;
+    const double t = 6.0 + p.per * large_ktile(wgs) + 0.29 * wgs / 4.0;
+    if (t < best) best = t, plan = p;
+  }
+  return plan;
 }
 
 // The workspace of the split: one per device and stream (launches on one stream follow one another; two streams may
@@ -2167,7 +2298,8 @@ float* split_workspace(hipStream_t st) {
   for (const Ws& w : all)
     if (w.dev == dev && w.st == st) return w.p;
   float* p = nullptr;
-  if (hipMalloc((void**)&p, (size_t)kSplitMaxSlabs * 4 * kS128SlabFloats * sizeof(float)) != hipSuccess) {
+  static_assert(kW4SlabFloats >= kS128SlabFloats, "sized for the large tiles: 256 workgroups x 256 KiB");
+  if (hipMalloc((void**)&p, (size_t)kSplitMaxSlabs * 4 * kW4SlabFloats * sizeof(float)) != hipSuccess) {
     (void)hipGetLastError();
     p = nullptr;  // remembered: the caller runs unsplit, now and later
   }
@@ -2193,7 +2325,7 @@ int launch_gemm_t(const GemmArgs& g) {
   // (0, 1, 3, 4, 5 and 7) all stay on the K=32 one, for every shape.
   constexpr bool kFp8 = DT == GMD_DT_FP8;
   const int asked = gemm_variant();
-  const bool fp8_wide = kFp8 && (asked < 0 || asked > kVariantMax || asked == 2 || asked == 6 || asked == 8 || asked == 9);
+  const bool fp8_wide = kFp8 && (asked < 0 || asked > kVariantMax || asked == 2 || asked == 6 || asked == 8 || asked == 9 || asked == 10);
   // Small problems and ragged edges (bf16 and unscaled fp8; MX-fp8 has no small-tile kernel).
   // * Where the 256 x 256 tiles leave CUs idle, 128 x 128 tiles (schedule 8) fill them: taken when every CU gets at
   //   most one small tile (2048^3: 64 large tiles on 256 CUs, or 256 small ones).  With several small tiles per CU the
@@ -2229,17 +2361,31 @@ int launch_gemm_t(const GemmArgs& g) {
     };
     const S128Region whole_matrix{(const char*)g.a, (const char*)g.b, (__bf16*)g.c, g.m, g.n}, none{nullptr, nullptr, nullptr, 0, 0};
     const bool automatic = asked < 0 || asked > kVariantMax;
-    if (asked == 9 || (automatic && tiles128(g.m, g.n) <= cus)) {
-      const int tiles = tiles128(g.m, g.n), splits = split_k_count(tiles, (int)ktiles, asked == 9);
-      float* const work = splits > 1 ? split_workspace(g.st) : nullptr;
-      if (work) {
+    // Split along K where the model (plan_split) has it ahead, or where it is asked for.
+    if ((asked == 9 || asked == 10 || automatic) && !g.ldc && !g.reg_sum) {
+      const SplitPlan plan = plan_split(g.m, g.n, (int)ktiles, automatic ? -1 : asked);
+      float* const work = plan.schedule ? split_workspace(g.st) : nullptr;
+      if (work && plan.schedule == 10) {
+        GemmArgs part = g;
+        part.c = work;
+        part.ldc = plan.per;
+        int rc;  // (unscaled fp8 is on the K=128 instruction here: asked for or automatic)
+        if constexpr (kFp8) rc = launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 4, false, false, true>, grid * plan.splits, kThreadsW4, kLdsBytes, part);
+        else rc = launch_lds(gemm_w4_kernel<DT, 0, 4>, grid * plan.splits, kThreadsW4, kLdsBytes, part);
+        if (rc) return rc;
+        gemm_w4_reduce_kernel<<<grid * 8, 256, 0, g.st>>>(work, plan.splits, grid, g.n / BN, (__bf16*)g.c, (size_t)g.n);
+        GMD_HIP(hipGetLastError());
+        return GMD_OK;
+      }
+      if (work && plan.schedule == 9) {
+        const int tiles = tiles128(g.m, g.n);
         S128Args a;
         a.r[0] = whole_matrix, a.r[1] = none;
         a.tiles0 = tiles;
         a.ldc = ldc;
         a.row_bytes = g.row_bytes;
         a.work = work;
-        a.kt_per_split = ((int)ktiles + splits - 1) / splits;
+        a.kt_per_split = plan.per;
         thread_local int attr_dev = -1;
         int dev = 0;
         GMD_HIP(hipGetDevice(&dev));
@@ -2248,9 +2394,9 @@ int launch_gemm_t(const GemmArgs& g) {
                                       kS128LdsBytes));
           attr_dev = dev;
         }
-        gemm_s128_kernel<DT, kS128Stages, true><<<tiles * splits, kS128Threads, kS128LdsBytes, g.st>>>(a);
+        gemm_s128_kernel<DT, kS128Stages, true><<<tiles * plan.splits, kS128Threads, kS128LdsBytes, g.st>>>(a);
         GMD_HIP(hipGetLastError());
-        gemm_s128_reduce_kernel<<<tiles * 4, kS128Threads, 0, g.st>>>(work, splits, tiles, (__bf16*)g.c, g.m, g.n, ldc);
+        gemm_s128_reduce_kernel<<<tiles * 4, kS128Threads, 0, g.st>>>(work, plan.splits, tiles, (__bf16*)g.c, g.m, g.n, ldc);
         GMD_HIP(hipGetLastError());
         return GMD_OK;
       }
@@ -2386,15 +2532,29 @@ int gmd_gemm_set_variant(int variant) {
   return GMD_OK;
 }
 
-// Into how many ranges of K the schedule in force splits a GEMM of this shape (1: not at all).
-int gmd_gemm_split_k(int dtype, int m, int n, int k) {
-  if ((dtype != GMD_DT_BF16 && dtype != GMD_DT_FP8) || m <= 0 || n <= 0 || k <= 0) return 1;
+// What the schedule in force does with a GEMM of this shape on the current device: *schedule 9 or 10 and *splits ranges
+// of K, or *schedule 0 and one range (no split; which unsplit kernel runs is launch_gemm_t's business).
+int gmd_gemm_plan(int dtype, int m, int n, int k, int* schedule, int* splits) {
+  if (schedule) *schedule = 0;
+  if (splits) *splits = 1;
+  if ((dtype != GMD_DT_BF16 && dtype != GMD_DT_FP8) || m <= 0 || n <= 0 || k <= 0) return GMD_OK;
   const int asked = gemm_variant();
   const bool automatic = asked < 0 || asked > kVariantMax;
-  if (!automatic && asked != 9) return 1;
-  const int tiles = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
-  if (automatic && tiles > persistent_grid()) return 1;
-  return split_k_count(tiles, (int)((size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB), asked == 9);
+  if (!automatic && asked != 9 && asked != 10) return GMD_OK;
+  const SplitPlan p = plan_split(m, n, (int)((size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB), automatic ? -1 : asked);
+  if (schedule) *schedule = p.schedule;
+  if (splits) *splits = p.splits;
+  return GMD_OK;
+}
+int gmd_gemm_split_k(int dtype, int m, int n, int k) {
+  int splits = 1;
+  gmd_gemm_plan(dtype, m, n, k, nullptr, &splits);
+  return splits;
+}
+int gmd_gemm_set_split(int splits) {
+  if (splits < 0 || splits == 1 || splits > kSplitMax) return GMD_ERR_BADPARAM;
+  g_gemm_splits = splits;
+  return GMD_OK;
 }
 
 // Ablation builds only: per-workgroup (shader ticks, 100 MHz ticks) pairs of the last stamped launch.
@@ -2430,6 +2590,7 @@ static bool reg_sum_shape(int dtype, int m, int n, int k) {
   if (asked >= 0 && asked <= kVariantMax) return false;
   const size_t ktiles = (size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB;
   const int tiles128 = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
+  if (dtype != GMD_DT_MXFP8 && plan_split(m, n, (int)ktiles, -1).schedule) return false;  // runs split along K
   return m % BM == 0 && n % BN == 0 && ktiles >= 2 && ktiles % 2 == 0 && (dtype == GMD_DT_MXFP8 || tiles128 > persistent_grid());
 }
 

@@ -209,16 +209,33 @@ def gemm_set_variant(variant):
     as one stream per CU over its tiles, 4 / 5 = schedule 1 with the narrow / cached epilogue, 6 = schedule 2 as one
     stream per CU (A/B reference; slower than 2, see docs/diagnostics.md), 7 = schedule 2 on the K=32 fp8 instruction
     (unscaled fp8 runs -1, 2 and 6 on the K=128 instruction, at twice the rate, and the others on the K=32 one),
-    8 = 128 x 128 tiles, 9 = 128 x 128 tiles split along K where they fill at most half of the CUs (see gemm_split_k)."""
+    8 = 128 x 128 tiles, 9 / 10 = small / large tiles split along K (see gemm_plan)."""
     rc = _lib().gmd_gemm_set_variant(int(variant))
     if rc:
         raise DiagError(rc, "gmd_gemm_set_variant")
 
 
+def gemm_plan(dtype, m, n, k):
+    """What the schedule in force does with a GEMM of this shape on the current device: (9 or 10, number of K ranges)
+    where it runs split along K (small / large tiles), (0, 1) where it does not.  A split GEMM adds its products up
+    in another order than the unsplit schedules, the same one at every launch."""
+    schedule, splits = C.c_int(0), C.c_int(1)
+    rc = _lib().gmd_gemm_plan(DTYPES[dtype], int(m), int(n), int(k), C.byref(schedule), C.byref(splits))
+    if rc:
+        raise DiagError(rc, "gmd_gemm_plan")
+    return schedule.value, splits.value
+
+
 def gemm_split_k(dtype, m, n, k):
-    """Number of K ranges the schedule in force splits a GEMM of this shape into on the current device (1 = no split).
-    A split GEMM adds its products up in another order than the unsplit schedules, the same one at every launch."""
-    return int(_lib().gmd_gemm_split_k(DTYPES[dtype], int(m), int(n), int(k)))
+    """Number of K ranges of gemm_plan() alone (1 = no split)."""
+    return gemm_plan(dtype, m, n, k)[1]
+
+
+def gemm_set_split(splits):
+    """Number of K ranges schedules 9 and 10 use when asked for (2..8); 0 = as many as fit."""
+    rc = _lib().gmd_gemm_set_split(int(splits))
+    if rc:
+        raise DiagError(rc, "gmd_gemm_set_split")
 
 
 COLLECTIVES = {"all_reduce": 0, "all_gather": 1, "reduce_scatter": 2, "all_to_all": 3, "broadcast": 4}

@@ -26,6 +26,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # LDS requested at launch (bytes), by kernel-name pattern: the GEMM kernels take a 128 KiB operand ring,
 # the four-wave MX-fp8 kernel (first template argument 3 = MX-fp8) 8 KiB more for its scale ring.
 DYNAMIC_LDS = [
+    (re.compile(r"gemm_w4_kernel<3,.*true>$"), 131072),  # unit scales: no scale ring
     (re.compile(r"gemm_w4_kernel<3,"), 131072 + 8192),
     (re.compile(r"gemm_s128_kernel<"), 163840),  # five stages of 32 KiB: all of a CU's LDS
     (re.compile(r"gemm_(pp|ps|w4)?_?kernel<"), 131072),

@@ -291,15 +291,15 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
                           (4352, 4352, 4 * kt), (4352, 4608, 10 * kt)]:  # 289 / 306 tiles: more than CUs, variant 3 streams
             G = _Gemm(diag, dev, m, n, k, dtype, seed=k)
             outs = {}
-            splits = {}
-            for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, -1):
+            plans = {}
+            for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, -1):
                 diag.gemm_set_variant(variant)
-                splits[variant] = diag.gemm_split_k(dtype, m, n, k)
+                plans[variant] = diag.gemm_plan(dtype, m, n, k)
                 c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
                 G.launch(c)
                 torch.cuda.synchronize()
                 outs[variant] = c
-                if variant in (1, 2, 3, 6, 7, 8, 9):  # 4 and 5 differ from 1 in the epilogue only
+                if variant in (1, 2, 3, 6, 7, 8, 9, 10):  # 4 and 5 differ from 1 in the epilogue only
                     c2 = torch.empty_like(c)
                     for _ in range(20):
                         G.launch(c2)
@@ -307,17 +307,28 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
                     assert torch.equal(c2, c), (variant, m, n, k)
             # Unscaled fp8: the default, 2 and 6 run on the K=128 instruction, which adds the same products up in another
             # order; 7 is schedule 2 on the K=32 instruction.  Each group is identical within itself.
-            # A GEMM split along K (9, and the default for few tiles and many K-tiles: 512 x 512 x 32 K-tiles in 4,
-            # 1024 x 768 x 128 in 5) adds up in an order of its own: the same for every launch and for the same number of
-            # splits, and as close to fp32 as the others.
-            wide = (2, 6, 8, 9, -1) if dtype == "fp8" else ()
-            assert all(splits[v] == 1 for v in range(9)) and (dtype != "mxfp8" or splits[9] == splits[-1] == 1)
-            assert splits[-1] == ({(512, 512, 32 * kt): 4, (1024, 768, 128 * kt): 5}.get((m, n, k), 1) if dtype != "mxfp8" else 1)
-            for variant in (1, 2, 3, 4, 5, 6, 7, -1) + (() if dtype == "mxfp8" else (8, 9)):
-                if splits[variant] > 1:
+            # A GEMM split along K (9 on small tiles, 10 on large ones, and the default for few tiles and a long K: 512 x 512
+            # x 32 K-tiles and 1024 x 768 x 128 here) adds up in an order of its own: the same for every launch and, for the
+            # same kernel and number of ranges, the same whether asked for or chosen; as close to fp32 as the others.
+            wide = (2, 6, 8, 9, 10, -1) if dtype == "fp8" else ()
+            assert all(plans[v] == (0, 1) for v in range(9)) and (dtype != "mxfp8" or plans[9] == plans[10] == plans[-1] == (0, 1))
+            assert (plans[-1][0] != 0) == (dtype != "mxfp8" and (m, n, k) in ((512, 512, 32 * kt), (1024, 768, 128 * kt))), plans[-1]
+            for variant in (1, 2, 3, 4, 5, 6, 7, -1) + (() if dtype == "mxfp8" else (8, 9, 10)):
+                schedule, ranges = plans[variant]
+                if schedule:
                     ref = G.ref()
                     assert ((outs[variant].float() - ref).abs().max() / ref.abs().max()).item() < 6e-3, (variant, m, n, k)
-                    assert splits[variant] != splits[9] or torch.equal(outs[variant], outs[9]), (variant, m, n, k)
+                    if variant == -1:  # the same schedule asked for, with the same number of ranges
+                        diag.gemm_set_variant(schedule)
+                        diag.gemm_set_split(ranges)
+                        try:
+                            assert diag.gemm_plan(dtype, m, n, k) == (schedule, ranges)
+                            c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+                            G.launch(c)
+                            torch.cuda.synchronize()
+                        finally:
+                            diag.gemm_set_split(0)
+                        assert torch.equal(c, outs[-1]), (schedule, ranges, m, n, k)
                     continue
                 assert torch.equal(outs[2 if variant in wide else 0], outs[variant]), (variant, m, n, k)
             if wide:
@@ -325,7 +336,7 @@ def test_gemm_schedules_agree_bit_for_bit(diag, dev, dtype):
                 for v in (0, 2):
                     assert ((outs[v].float() - ref).abs().max() / ref.abs().max()).item() < 6e-3, (v, m, n, k)
         with pytest.raises(diag.DiagError):
-            diag.gemm_set_variant(10)
+            diag.gemm_set_variant(99)
     finally:
         diag.gemm_set_variant(-1)
 
@@ -377,13 +388,16 @@ def test_gemm_takes_the_operators_shape(diag, dev, dtype, shape):
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 def test_gemm_split_along_k(diag, dev, dtype):
     """Few tiles and a long K: the default gives every tile to several workgroups, each over a range of K-tiles, and adds
-    their fp32 sums up in a second kernel.  Ragged shapes (rows and columns beyond the matrix, a last range shorter than
-    the others), a guard band behind C, the same bits at every launch, and two streams at once (each has a workspace of
-    its own, so neither reads the other's partial sums)."""
+    their fp32 sums up in a second kernel: on small tiles (schedule 9) or, where K is long enough to pay for their larger
+    partial sums, on large ones (schedule 10).  Ragged shapes (rows and columns beyond the matrix, a last range shorter
+    than the others), a guard band behind C, the same bits at every launch, and two streams at once (each has a
+    workspace of its own, so neither reads the other's partial sums)."""
     kt = 64 if dtype == "bf16" else 128
-    for (m, n, ktiles, want) in [(1024, 1024, 64, 4), (1000, 520, 40, 5), (128, 128, 100, 8), (1024, 2048, 33, 2), (2048, 2048, 64, 1)]:
+    for (m, n, ktiles, want) in [(1024, 1024, 64, 9), (1000, 520, 40, 9), (128, 128, 100, 9), (1024, 2048, 33, 0), (2048, 2048, 64, 0),
+                                 (2048, 2048, 128, 10), (2048, 4096, 128, 10), (1536, 1024, 130, 10)]:
         k = ktiles * kt
-        assert diag.gemm_split_k(dtype, m, n, k) == want, (m, n, k)
+        schedule, ranges = diag.gemm_plan(dtype, m, n, k)
+        assert schedule == want and (ranges > 1) == (want != 0), (m, n, k, schedule, ranges)
         G = _Gemm(diag, dev, m, n, k, dtype, seed=m + k)
         guard = 4096
         buf = torch.full((m * n + guard,), 7.0, dtype=torch.bfloat16, device=dev)
