@@ -924,6 +924,10 @@ int cmd_gemm(const Args& a, Report& r, int gpu, MfmaWatch* mfma) {
            name.c_str(), m, n, k, gpu, g.tflops, g.tflops_best, want > 0 ? strprintf_local(", expected %.0f", want).c_str() : "",
            (unsigned long long)g.launches, g.seconds, (unsigned long long)g.sdc_mismatches, g.max_rel_err,
            g.verified > 0 ? "ok" : g.verified < 0 ? "WRONG" : "skipped");
+    int schedule = 0, ranges = 1;
+    if (gmd_gemm_plan(dt, m, n, k, &schedule, &ranges) == GMD_OK && schedule)
+      r.text("  schedule: split along K into %d ranges on %s tiles, partial sums added up in a fixed order\n", ranges,
+             schedule == 10 ? "256x256" : "128x128");
     if (g.verified)
       r.text("  integrity: %llu launches summed in the kernel's epilogue and held against the first, %llu re-read from memory\n",
              (unsigned long long)g.checked_in_kernel, (unsigned long long)g.checked_in_memory);
@@ -931,7 +935,7 @@ int cmd_gemm(const Args& a, Report& r, int gpu, MfmaWatch* mfma) {
            jnum(g.tflops_best) + ",\"expected_tflops\":" + (want > 0 ? jnum(want) : "null") + ",\"launches\":" + std::to_string(g.launches) +
            ",\"sdc_mismatches\":" + std::to_string(g.sdc_mismatches) + ",\"max_rel_err\":" + jnum(g.max_rel_err) + ",\"verified\":" +
            std::to_string(g.verified) + ",\"checked_in_kernel\":" + std::to_string(g.checked_in_kernel) + ",\"checked_in_memory\":" +
-           std::to_string(g.checked_in_memory);
+           std::to_string(g.checked_in_memory) + ",\"split_k\":" + std::to_string(ranges);
     if (mfma) {  // the windows that lie inside this dtype's soak
       usleep(300000);  // let the window that ends with the soak arrive
       int wn = 0;
