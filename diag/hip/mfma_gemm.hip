@@ -2295,8 +2295,14 @@ float* split_workspace(hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  for (const Ws& w : all)
+  int held = 0;
+  for (const Ws& w : all) {
     if (w.dev == dev && w.st == st) return w.p;
+    held += w.dev == dev && w.p;
+  }
+  // Eight streams of a device get a workspace (64 MiB each); a process that goes on making streams runs its further
+  // GEMMs unsplit rather than growing without bound (a workspace is never taken back: a launch may still be using it).
+  if (held >= 8) return nullptr;
   float* p = nullptr;
   static_assert(kW4SlabFloats >= kS128SlabFloats, "sized for the large tiles: 256 workgroups x 256 KiB");
   if (hipMalloc((void**)&p, (size_t)kSplitMaxSlabs * 4 * kW4SlabFloats * sizeof(float)) != hipSuccess) {
