@@ -1,0 +1,97 @@
+"""Which GEMM shapes run split along K, and into how many ranges (diag/hip/mfma_gemm.hip: plan_split).  The planner is
+host code: it runs here without a GPU, for a device of 256 CUs.  tests/data/gemm_split_sweep.json is a run of
+scripts/gpu_gemm_split_sweep.py on an MI355X (microseconds per launch of every schedule, of the automatic choice and of
+hipBLASLt at 90 shapes): the model's constants were fitted to it, so a change to them belongs with a new sweep."""
+import json
+import os
+
+import pytest
+
+from k8s_gpu_monitor_amd.ops import diag
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "build", "libgpumon_diag.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="needs the built diagnostics library")
+CUS = 256
+
+
+@pytest.fixture(autouse=True)
+def _automatic():
+    diag.gemm_set_variant(-1)
+    diag.gemm_set_split(0)
+    yield
+    diag.gemm_set_variant(-1)
+    diag.gemm_set_split(0)
+
+
+def _ktiles(dtype, k):
+    return k * (2 if dtype == "bf16" else 1) // 128
+
+
+def test_the_plan_is_the_one_the_sweep_was_measured_with():
+    rows = json.load(open(os.path.join(ROOT, "tests", "data", "gemm_split_sweep.json")))
+    assert len(rows) == 90
+    for r in rows:
+        assert diag.gemm_plan(r["dtype"], r["m"], r["n"], r["k"]) == (r["auto_schedule"], r["auto_splits"]), r
+    # ... and that choice was a good one: within 5 % of the best schedule asked for by hand nearly everywhere, never
+    # more than 12 % behind it, and level with the vendor's kernel (2 %) at three shapes in four
+    behind = [r["auto"] / min(r["v2"], r["v8"], r["v9"], r["v10"]) for r in rows]
+    assert sum(b > 1.05 for b in behind) <= 4 and max(behind) < 1.12, sorted(behind)[-5:]
+    assert sum(r["auto"] <= 1.02 * r["vendor"] for r in rows) >= 66
+
+
+def test_a_plan_fits_the_chip_and_the_kernels():
+    for dtype in ("bf16", "fp8"):
+        for m in (128, 256, 520, 1000, 1024, 1536, 2048, 3072, 4096, 8192):
+            for n in (128, 512, 1024, 2048, 4104):
+                for k in (128, 640, 2048, 4096, 8192 + 128, 16384, 65536):
+                    schedule, ranges = diag.gemm_plan(dtype, m, n, k)
+                    kt = _ktiles(dtype, k)
+                    assert schedule in (0, 9, 10) and (ranges == 1) == (schedule == 0), (dtype, m, n, k)
+                    if schedule == 9:
+                        tiles = -(-m // 128) * -(-n // 128)
+                        assert 2 <= ranges <= 8 and tiles * ranges <= CUS and -(-kt // ranges) >= 4
+                    if schedule == 10:  # whole large tiles, K-tiles in pairs, every range a whole number of pairs
+                        assert m % 256 == 0 and n % 256 == 0 and kt % 2 == 0
+                        per = (-(-kt // ranges) + 1) & ~1
+                        assert 2 <= ranges <= 8 and (m // 256) * (n // 256) * ranges <= CUS and per >= 16
+                        assert (ranges - 1) * per < kt  # no range without a K-tile
+    for shape in [(8192, 8192, 8192), (4096, 4096, 65536), (16384, 1024, 16384), (2048, 2048, 2048), (1024, 1024, 1024)]:
+        assert diag.gemm_plan("bf16", *shape) == (0, 1), shape  # the chip is full, or K too short to pay for a second launch
+    assert diag.gemm_plan("mxfp8", 1024, 1024, 16384) == (0, 1)  # the scaled kernel has no split
+
+
+def test_a_longer_k_never_ends_a_split():
+    for dtype in ("bf16", "fp8"):
+        for (m, n) in [(512, 512), (1024, 1024), (1000, 520), (1536, 1024), (2048, 2048), (4096, 2048)]:
+            split = False
+            for k in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+                now = diag.gemm_plan(dtype, m, n, k)[0] != 0
+                assert now or not split, (dtype, m, n, k)
+                split = now
+            assert split, (dtype, m, n)
+
+
+def test_schedules_asked_for_split_as_far_as_they_can():
+    diag.gemm_set_variant(9)
+    assert diag.gemm_plan("bf16", 1024, 1024, 4096) == (9, 4)     # 64 tiles: four ranges fill 256 CUs
+    assert diag.gemm_plan("bf16", 256, 256, 128) == (9, 2)        # two K-tiles: two ranges of one
+    assert diag.gemm_plan("bf16", 256, 256, 64) == (0, 1)
+    assert diag.gemm_plan("bf16", 2048, 2048, 8192) == (0, 1)     # one tile per CU already
+    diag.gemm_set_split(2)
+    assert diag.gemm_plan("bf16", 1024, 1024, 4096) == (9, 2)
+    diag.gemm_set_split(8)
+    assert diag.gemm_plan("bf16", 1024, 1024, 4096) == (0, 1)     # 512 workgroups do not fit: runs unsplit
+    diag.gemm_set_split(0)
+    diag.gemm_set_variant(10)
+    assert diag.gemm_plan("bf16", 2048, 2048, 8192) == (10, 4)
+    assert diag.gemm_plan("bf16", 256, 256, 256) == (10, 2)       # four K-tiles: two ranges of a pair
+    assert diag.gemm_plan("bf16", 256, 256, 384) == (10, 3)       # six: three ranges of a pair
+    assert diag.gemm_plan("bf16", 1000, 520, 8192) == (0, 1)      # partial tiles
+    assert diag.gemm_plan("bf16", 256, 256, 64 * 5) == (0, 1)     # an odd number of K-tiles
+    diag.gemm_set_variant(2)
+    assert diag.gemm_plan("bf16", 1024, 1024, 4096) == (0, 1)
+    with pytest.raises(diag.DiagError):
+        diag.gemm_set_split(1)
+    with pytest.raises(diag.DiagError):
+        diag.gemm_set_split(9)
