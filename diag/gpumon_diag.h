@@ -203,7 +203,8 @@ GMD_API int gmd_mx_pack_scales(const void* scales_row_major, void* packed, int r
  * 8 = 128 x 128 tiles, four waves of 64 x 64, two workgroups per CU (bf16 and fp8, any M, N in multiples of 8): what
  * the default picks where the 256 x 256 tiles cannot fill the chip (2048^3 is 64 of them on 256 CUs); MX-fp8 runs 2.
  * 9 = schedule 8 split along K: several workgroups share a tile, each over a range of K-tiles, and a second kernel adds
- * their fp32 sums up in a fixed order; 10 = the same on the 256 x 256 tiles of schedule 2 (whole tiles, K-tiles in pairs).
+ * their fp32 sums up in a fixed order; 10 = the same on the 256 x 256 tiles of schedule 2 (whole tiles, K-tiles in pairs;
+ * MX-fp8 as well, which has no schedule 9).
  * Asked for, they split into as many ranges as fit (at most 8 and one workgroup per CU), or into gmd_gemm_set_split()
  * ranges; where a shape cannot be split, 8 and 2 run.  The default takes one of them where a model of the launch times
  * has it ahead (few tiles and a long K: 1024 x 1024 x 4096, 2048 x 2048 x 8192); gmd_gemm_plan() says what a shape gets.

@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   // K-tiles (the last range what is left) of tile b % tiles from K-tile (b / tiles) * ldc on and leaves its fp32
   // accumulators, as they are, in the workspace that C points to (gemm_w4_reduce_kernel adds the ranges up and stores C).
   constexpr bool kSplit = EPI == 4;
-  static_assert(!kSplit || (!STREAM && !GEN && !kScaled && ABL == 0), "the split runs whole tiles of bf16 or unscaled fp8");
+  static_assert(!kSplit || (!STREAM && !GEN && ABL == 0), "the split runs whole tiles and pairs of K-tiles");
   const int tiles_m = GEN ? (M + BM - 1) / BM : M / BM, tiles_n = GEN ? (N + BN - 1) / BN : N / BN;
   const int nunits = STREAM || kSplit ? tiles_m * tiles_n : (int)gridDim.x;
   int bid = (int)blockIdx.x, split = 0;
@@ -1214,8 +1214,9 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   const int ktiles = (int)(row_bytes / BKB);
   char* const my_scales = smem + kLdsBytes + wave * 8 * 256;
   auto scale_base = [&](const uint32_t* S, int t, int w) { return S + (size_t)(4 * t + 2 * w) * ktiles * kScaleUnitDwords; };
-  const uint32_t* sc_a = kScaled ? scale_base(SA, tm, wr) : nullptr;  // wave-uniform
-  const uint32_t* sc_b = kScaled ? scale_base(SB, tn, wc) : nullptr;
+  // (a split GEMM's range of K begins kt_first units into the tile's run of units)
+  const uint32_t* sc_a = kScaled ? scale_base(SA, tm, wr) + (size_t)kt_first * kScaleUnitDwords : nullptr;  // wave-uniform
+  const uint32_t* sc_b = kScaled ? scale_base(SB, tn, wc) + (size_t)kt_first * kScaleUnitDwords : nullptr;
   const uint32_t* nsc_a = kScaled && has_next ? scale_base(SA, ntm, wr) : sc_a;
   const uint32_t* nsc_b = kScaled && has_next ? scale_base(SB, ntn, wc) : sc_b;
   uint32_t lane_x4 = (uint32_t)lane * 4;
@@ -2242,12 +2243,13 @@ SplitPlan large_split(int m, int n, int ktiles, int s) {
   return eff >= 2 ? SplitPlan{10, eff, per} : SplitPlan{0, 1, ktiles};
 }
 
-SplitPlan plan_split(int m, int n, int ktiles, int asked) {
+SplitPlan plan_split(int m, int n, int ktiles, int asked, bool large_only = false) {  // large_only: MX-fp8 has no small-tile kernel
   const int cus = persistent_grid();
-  const int t128 = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
+  const int t128 = large_only ? 0 : ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
   const bool whole = m % BM == 0 && n % BN == 0 && ktiles >= 2 && (ktiles & 1) == 0;
   const int large = whole ? (m / BM) * (n / BN) : 0;
   const SplitPlan none{0, 1, ktiles};
+  if (large_only && asked == 9) return none;
   if (asked == 9 || asked == 10) {  // the largest number of ranges that fits, or the number set
     for (int s = g_gemm_splits ? g_gemm_splits : kSplitMax; s >= 2; s--) {
       const SplitPlan p = asked == 9 ? small_split(t128, ktiles, s) : large_split(m, n, ktiles, s);
@@ -2261,7 +2263,7 @@ SplitPlan plan_split(int m, int n, int ktiles, int asked) {
   auto small_ktile = [&](int wgs) { return 0.475 * (1.0 + 0.15 * busy(wgs) * busy(wgs)); };
   auto large_ktile = [&](int wgs) { return 0.9 + 0.35 * busy(wgs) * busy(wgs) * busy(wgs); };
   // what runs unsplit: small tiles while every CU gets at most one, large tiles beyond (launch_gemm_t)
-  double best = t128 <= cus ? 4.0 + ktiles * small_ktile(t128) : large ? 5.5 + rounds(large) * ktiles * 0.89 : 0.0;
+  double best = t128 > 0 && t128 <= cus ? 4.0 + ktiles * small_ktile(t128) : large ? 5.5 + rounds(large) * ktiles * 0.89 : 0.0;
   if (best == 0.0) return none;  // more small tiles than CUs and no whole large tiles: the general kernel
   best *= 0.97;
   SplitPlan plan = none;
@@ -2342,6 +2344,23 @@ int launch_gemm_t(const GemmArgs& g) {
   //   (ldc) stays the full width.  Taken when the model says it saves at least a tenth: a round of large tiles is 1,
   //   a round of small ones 1 / (4 x 0.57) (measured at 8192^3).
   // Schedule 8 asks for small tiles whatever the shape.
+  if constexpr (kMx) {  // MX-fp8: large tiles only, split along K where the model has it ahead (or schedule 10 asks)
+    const bool automatic = asked < 0 || asked > kVariantMax;
+    if ((asked == 10 || automatic) && !g.ldc && !g.reg_sum && full_tiles) {
+      const SplitPlan plan = plan_split(g.m, g.n, (int)ktiles, automatic ? -1 : 10, true);
+      float* const work = plan.schedule == 10 ? split_workspace(g.st) : nullptr;
+      if (work) {
+        GemmArgs part = g;
+        part.c = work;
+        part.ldc = plan.per;
+        const int rc = launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 4>, grid * plan.splits, kThreadsW4, kLdsBytes + kScaleRingBytes, part);
+        if (rc) return rc;
+        gemm_w4_reduce_kernel<<<grid * 8, 256, 0, g.st>>>(work, plan.splits, grid, g.n / BN, (__bf16*)g.c, (size_t)g.n);
+        GMD_HIP(hipGetLastError());
+        return GMD_OK;
+      }
+    }
+  }
   if constexpr (!kMx) {
     const int cus = persistent_grid();
     auto tiles128 = [](int m, int n) { return ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128); };
@@ -2543,11 +2562,11 @@ int gmd_gemm_set_variant(int variant) {
 int gmd_gemm_plan(int dtype, int m, int n, int k, int* schedule, int* splits) {
   if (schedule) *schedule = 0;
   if (splits) *splits = 1;
-  if ((dtype != GMD_DT_BF16 && dtype != GMD_DT_FP8) || m <= 0 || n <= 0 || k <= 0) return GMD_OK;
+  if ((dtype != GMD_DT_BF16 && dtype != GMD_DT_FP8 && dtype != GMD_DT_MXFP8) || m <= 0 || n <= 0 || k <= 0) return GMD_OK;
   const int asked = gemm_variant();
   const bool automatic = asked < 0 || asked > kVariantMax;
   if (!automatic && asked != 9 && asked != 10) return GMD_OK;
-  const SplitPlan p = plan_split(m, n, (int)((size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB), automatic ? -1 : asked);
+  const SplitPlan p = plan_split(m, n, (int)((size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB), automatic ? -1 : asked, dtype == GMD_DT_MXFP8);
   if (schedule) *schedule = p.schedule;
   if (splits) *splits = p.splits;
   return GMD_OK;
@@ -2596,7 +2615,7 @@ static bool reg_sum_shape(int dtype, int m, int n, int k) {
   if (asked >= 0 && asked <= kVariantMax) return false;
   const size_t ktiles = (size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB;
   const int tiles128 = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
-  if (dtype != GMD_DT_MXFP8 && plan_split(m, n, (int)ktiles, -1).schedule) return false;  // runs split along K
+  if (plan_split(m, n, (int)ktiles, -1, dtype == GMD_DT_MXFP8).schedule) return false;  // runs split along K
   return m % BM == 0 && n % BN == 0 && ktiles >= 2 && ktiles % 2 == 0 && (dtype == GMD_DT_MXFP8 || tiles128 > persistent_grid());
 }
 

@@ -21,10 +21,10 @@ def test_no_accumulator_is_read_before_the_matrix_pipe_is_drained():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert r.returncode == 0, r.stdout + r.stderr
     # three data types x (per tile, general, stream), the per-tile kernels once more with the summing epilogue of the soak,
-    # and bf16 and unscaled fp8 with the epilogue of a GEMM split along K (fp32 accumulators to the workspace)
-    assert len(lines) == 18 and all(ln.endswith(": ok") for ln in lines), r.stdout
+    # and all three with the epilogue of a GEMM split along K (fp32 accumulators to the workspace)
+    assert len(lines) == 19 and all(ln.endswith(": ok") for ln in lines), r.stdout
     assert sum(", 0, 3, false, false" in ln for ln in lines) == 4, r.stdout
-    assert sum(", 0, 4, false, false" in ln for ln in lines) == 2, r.stdout
+    assert sum(", 0, 4, false, false" in ln for ln in lines) == 3, r.stdout
 
 
 def test_the_checker_sees_a_read_that_comes_too_early():

@@ -58,7 +58,9 @@ def test_a_plan_fits_the_chip_and_the_kernels():
                         assert (ranges - 1) * per < kt  # no range without a K-tile
     for shape in [(8192, 8192, 8192), (4096, 4096, 65536), (16384, 1024, 16384), (2048, 2048, 2048), (1024, 1024, 1024)]:
         assert diag.gemm_plan("bf16", *shape) == (0, 1), shape  # the chip is full, or K too short to pay for a second launch
-    assert diag.gemm_plan("mxfp8", 1024, 1024, 16384) == (0, 1)  # the scaled kernel has no split
+    # MX-fp8 has no small-tile kernel: large tiles or nothing
+    assert diag.gemm_plan("mxfp8", 1024, 1024, 16384) == (10, 8) and diag.gemm_plan("mxfp8", 1024, 1024, 1024) == (0, 1)
+    assert diag.gemm_plan("fp8", 1024, 1024, 4096)[0] == 9 and diag.gemm_plan("mxfp8", 1024, 1024, 4096)[0] in (0, 10)
 
 
 def test_a_longer_k_never_ends_a_split():
@@ -89,6 +91,9 @@ def test_schedules_asked_for_split_as_far_as_they_can():
     assert diag.gemm_plan("bf16", 256, 256, 384) == (10, 3)       # six: three ranges of a pair
     assert diag.gemm_plan("bf16", 1000, 520, 8192) == (0, 1)      # partial tiles
     assert diag.gemm_plan("bf16", 256, 256, 64 * 5) == (0, 1)     # an odd number of K-tiles
+    assert diag.gemm_plan("mxfp8", 2048, 2048, 8192) == (10, 4)
+    diag.gemm_set_variant(9)
+    assert diag.gemm_plan("mxfp8", 1024, 1024, 4096) == (0, 1)
     diag.gemm_set_variant(2)
     assert diag.gemm_plan("bf16", 1024, 1024, 4096) == (0, 1)
     with pytest.raises(diag.DiagError):
