@@ -67,12 +67,13 @@ for s in $STEPS; do
       D="$PWD/build/bin/gpumon-diag"
       for target in "gemm_bf16:gemm --dtype bf16 --seconds 0.05 --no-telemetry --no-expect" "gemm_fp8:gemm --dtype fp8 --seconds 0.05 --no-telemetry --no-expect" \
                     "gemm_mxfp8:gemm --dtype mxfp8 --seconds 0.05 --no-telemetry --no-expect" \
+                    "gemm_split:gemm --dtype bf16 --m 2048 --n 2048 --k 16384 --seconds 0.05 --no-telemetry --no-expect" \
                     "hbm:hbm --bytes 2G --iters 2 --no-expect" "memtest:memtest --bytes 4G --chunk 4G --patterns random,address --march --no-expect"; do
         name=${target%%:*}; args=${target#*:}
         buf=""  # buffer size of the streaming targets, for the expected-bytes columns
         [ "$name" = hbm ] && buf=2147483648
         [ "$name" = memtest ] && buf=4294967296
-        case " ${PMC_TARGETS:-gemm_bf16 gemm_fp8 gemm_mxfp8 hbm memtest} " in *" $name "*) ;; *) continue ;; esac
+        case " ${PMC_TARGETS:-gemm_bf16 gemm_fp8 gemm_mxfp8 gemm_split hbm memtest} " in *" $name "*) ;; *) continue ;; esac
         step "pmc_sq_$name" 120 timeout -s KILL 100 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_UNALIGNED_STALL \
           --output-format csv -d "$PWD/$OUT/pmc_sq_$name" -o p -- "$D" $args
         step "pmc_rd_$name" 120 timeout -s KILL 100 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$PWD/$OUT/pmc_rd_$name" -o p -- "$D" $args
