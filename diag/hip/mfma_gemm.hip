@@ -174,6 +174,14 @@ __device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* _
 // cannot see, a store or a memory cell that corrupts, the checksum pass over C (every Nth launch) still covers.
 __device__ unsigned long long g_gemm_reg_sum;
 
+// One atomic per wave into g_gemm_reg_sum (the kernels that add the ranges of a split GEMM up; store_acc_rows has its own).
+__device__ __forceinline__ void reg_sum_add(unsigned sum, int lane) {
+  unsigned long long wide = sum;
+#pragma unroll
+  for (int off = 32; off; off >>= 1) wide += __shfl_xor(wide, off, 64);
+  if (lane == 0) atomicAdd(&g_gemm_reg_sum, wide);
+}
+
 template <int EPI, bool PACE = false>
 __device__ __forceinline__ void store_acc_rows(const f32x4 (&acc)[8][8], __bf16* __restrict__ C, size_t ldc, int row0, int col0,
                                                int fr, int fq) {
@@ -271,6 +279,7 @@ constexpr size_t kW4SlabFloats = 64 * 64 * 4;  // per wave
 __device__ __forceinline__ f32x4* w4_slab(float* work, int split, int tiles, int tile, int wave) {
   return (f32x4*)(work + (((size_t)split * tiles + tile) * 4 + wave) * kW4SlabFloats);
 }
+template <bool SUM>  // SUM: the soak's instantiation, which adds the words it stores to g_gemm_reg_sum
 __global__ __launch_bounds__(256) void gemm_w4_reduce_kernel(const float* __restrict__ work, int splits, int tiles, int tiles_n,
                                                              __bf16* __restrict__ C, size_t ldc) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -288,13 +297,16 @@ __global__ __launch_bounds__(256) void gemm_w4_reduce_kernel(const float* __rest
     for (int nb = 0; nb < 8; nb++) acc[nb] += slab[(mb * 8 + nb) * 64 + lane];
   }
   __bf16* const base = C + (size_t)(tm * BM + wr * 128 + fq * 32) * ldc + tn * BN + wc * 128 + fr * 8;
+  unsigned sum = 0;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     u32x4 o;
 #pragma unroll
     for (int h = 0; h < 4; h++) o[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{acc[2 * h][r], acc[2 * h + 1][r]}, bf16x2));
     __builtin_nontemporal_store(o, (u32x4*)(base + (size_t)(r * 8 + mb) * ldc));
+    sum += (o[0] + o[1]) + (o[2] + o[3]);
   }
+  if constexpr (SUM) reg_sum_add(sum, lane);
 }
 
 // What the LDS-DMA of a K-tile beyond the last one reads when the K-tile count is odd (the pipelines walk K-tiles in
@@ -1921,9 +1933,10 @@ __device__ __forceinline__ f32x4* s128_slab(float* work, int split, int tiles, i
 // 16-lane rows of two adjacent blocks swap halves (v_permlane16_swap), after which every lane holds eight consecutive
 // columns of one block: 16-byte stores, each behind its bounds test.  `row` is the lane's row, `col0` the column of
 // its eight in the first pair of blocks.
-__device__ __forceinline__ void s128_store_blocks(const f32x4 (&acc)[4], __bf16* __restrict__ C, int M, int N, int ldc, int row, int col0) {
+__device__ __forceinline__ unsigned s128_store_blocks(const f32x4 (&acc)[4], __bf16* __restrict__ C, int M, int N, int ldc, int row, int col0) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  unsigned sum = 0;  // of the 32-bit words stored (the soak's check of every launch; unused elsewhere)
 #pragma unroll
   for (int nb = 0; nb < 4; nb += 2) {
     const u32x2 x = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[nb], bf16x4));
@@ -1932,8 +1945,12 @@ __device__ __forceinline__ void s128_store_blocks(const f32x4 (&acc)[4], __bf16*
     const u32x2 r1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
     const u32x4 o = u32x4{r0.x, r1.x, r0.y, r1.y};
     const int col = col0 + nb * 16;
-    if (row < M && col < N) __builtin_nontemporal_store(o, (u32x4*)(C + (size_t)row * ldc + col));  // N is a multiple of 8
+    if (row < M && col < N) {  // N is a multiple of 8
+      __builtin_nontemporal_store(o, (u32x4*)(C + (size_t)row * ldc + col));
+      sum += (o[0] + o[1]) + (o[2] + o[3]);
+    }
   }
+  return sum;
 }
 
 template <int DT, int NSTAGE = kS128Stages, bool SPLIT = false>
@@ -2130,6 +2147,7 @@ __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args arg
 // `splits` workgroups of the tile left in the workspace, always in the order of the splits (the result does not
 // depend on which workgroup finished first), and stores the tile's quarter as the unsplit kernel would.  Wave v of
 // the workgroup takes block row v.
+template <bool SUM>  // SUM: the soak's instantiation, which adds the words it stores to g_gemm_reg_sum
 __global__ __launch_bounds__(kS128Threads) void gemm_s128_reduce_kernel(const float* __restrict__ work, int splits, int tiles, __bf16* __restrict__ C,
                                                                         int M, int N, int ldc) {
   const int lane = threadIdx.x & 63, mb = threadIdx.x >> 6;
@@ -2145,7 +2163,8 @@ __global__ __launch_bounds__(kS128Threads) void gemm_s128_reduce_kernel(const fl
 #pragma unroll
     for (int nb = 0; nb < 4; nb++) acc[nb] += slab[(mb * 4 + nb) * 64 + lane];
   }
-  s128_store_blocks(acc, C, M, N, ldc, tm * kS128 + wr * 64 + fr + mb * 16, tn * kS128 + wc * 64 + (fq & 1) * 16 + (fq >> 1) * 8);
+  const unsigned sum = s128_store_blocks(acc, C, M, N, ldc, tm * kS128 + wr * 64 + fr + mb * 16, tn * kS128 + wc * 64 + (fq & 1) * 16 + (fq >> 1) * 8);
+  if constexpr (SUM) reg_sum_add(sum, lane);
 }
 
 constexpr int kVariantUnset = -2;
@@ -2346,7 +2365,7 @@ int launch_gemm_t(const GemmArgs& g) {
   // Schedule 8 asks for small tiles whatever the shape.
   if constexpr (kMx) {  // MX-fp8: large tiles only, split along K where the model has it ahead (or schedule 10 asks)
     const bool automatic = asked < 0 || asked > kVariantMax;
-    if ((asked == 10 || automatic) && !g.ldc && !g.reg_sum && full_tiles) {
+    if ((asked == 10 || automatic) && !g.ldc && full_tiles) {
       const SplitPlan plan = plan_split(g.m, g.n, (int)ktiles, automatic ? -1 : 10, true);
       float* const work = plan.schedule == 10 ? split_workspace(g.st) : nullptr;
       if (work) {
@@ -2355,7 +2374,8 @@ int launch_gemm_t(const GemmArgs& g) {
         part.ldc = plan.per;
         const int rc = launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 4>, grid * plan.splits, kThreadsW4, kLdsBytes + kScaleRingBytes, part);
         if (rc) return rc;
-        gemm_w4_reduce_kernel<<<grid * 8, 256, 0, g.st>>>(work, plan.splits, grid, g.n / BN, (__bf16*)g.c, (size_t)g.n);
+        if (g.reg_sum) gemm_w4_reduce_kernel<true><<<grid * 8, 256, 0, g.st>>>(work, plan.splits, grid, g.n / BN, (__bf16*)g.c, (size_t)g.n);
+        else gemm_w4_reduce_kernel<false><<<grid * 8, 256, 0, g.st>>>(work, plan.splits, grid, g.n / BN, (__bf16*)g.c, (size_t)g.n);
         GMD_HIP(hipGetLastError());
         return GMD_OK;
       }
@@ -2387,7 +2407,7 @@ int launch_gemm_t(const GemmArgs& g) {
     const S128Region whole_matrix{(const char*)g.a, (const char*)g.b, (__bf16*)g.c, g.m, g.n}, none{nullptr, nullptr, nullptr, 0, 0};
     const bool automatic = asked < 0 || asked > kVariantMax;
     // Split along K where the model (plan_split) has it ahead, or where it is asked for.
-    if ((asked == 9 || asked == 10 || automatic) && !g.ldc && !g.reg_sum) {
+    if ((asked == 9 || asked == 10 || automatic) && !g.ldc) {
       const SplitPlan plan = plan_split(g.m, g.n, (int)ktiles, automatic ? -1 : asked);
       float* const work = plan.schedule ? split_workspace(g.st) : nullptr;
       if (work && plan.schedule == 10) {
@@ -2398,7 +2418,8 @@ int launch_gemm_t(const GemmArgs& g) {
         if constexpr (kFp8) rc = launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 4, false, false, true>, grid * plan.splits, kThreadsW4, kLdsBytes, part);
         else rc = launch_lds(gemm_w4_kernel<DT, 0, 4>, grid * plan.splits, kThreadsW4, kLdsBytes, part);
         if (rc) return rc;
-        gemm_w4_reduce_kernel<<<grid * 8, 256, 0, g.st>>>(work, plan.splits, grid, g.n / BN, (__bf16*)g.c, (size_t)g.n);
+        if (g.reg_sum) gemm_w4_reduce_kernel<true><<<grid * 8, 256, 0, g.st>>>(work, plan.splits, grid, g.n / BN, (__bf16*)g.c, (size_t)g.n);
+        else gemm_w4_reduce_kernel<false><<<grid * 8, 256, 0, g.st>>>(work, plan.splits, grid, g.n / BN, (__bf16*)g.c, (size_t)g.n);
         GMD_HIP(hipGetLastError());
         return GMD_OK;
       }
@@ -2421,7 +2442,8 @@ int launch_gemm_t(const GemmArgs& g) {
         }
         gemm_s128_kernel<DT, kS128Stages, true><<<tiles * plan.splits, kS128Threads, kS128LdsBytes, g.st>>>(a);
         GMD_HIP(hipGetLastError());
-        gemm_s128_reduce_kernel<<<tiles * 4, kS128Threads, 0, g.st>>>(work, plan.splits, tiles, (__bf16*)g.c, g.m, g.n, ldc);
+        if (g.reg_sum) gemm_s128_reduce_kernel<true><<<tiles * 4, kS128Threads, 0, g.st>>>(work, plan.splits, tiles, (__bf16*)g.c, g.m, g.n, ldc);
+        else gemm_s128_reduce_kernel<false><<<tiles * 4, kS128Threads, 0, g.st>>>(work, plan.splits, tiles, (__bf16*)g.c, g.m, g.n, ldc);
         GMD_HIP(hipGetLastError());
         return GMD_OK;
       }
@@ -2608,14 +2630,15 @@ int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles) {
 #endif
 }
 
-// Shapes the summing epilogue exists for: what the default schedule runs as whole 256 x 256 tiles over K-tile pairs on
-// the four-wave kernel (not the small-tile kernel, not the general instantiation), with no schedule asked for.
+// Shapes a launch of which sums what it stores: what the default schedule runs as whole 256 x 256 tiles over K-tile
+// pairs on the four-wave kernel (not the unsplit small-tile kernel, not the general instantiation), and what it runs
+// split along K (the kernel that adds the ranges up sums); with no schedule asked for.
 static bool reg_sum_shape(int dtype, int m, int n, int k) {
   const int asked = gemm_variant();
   if (asked >= 0 && asked <= kVariantMax) return false;
   const size_t ktiles = (size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB;
   const int tiles128 = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
-  if (plan_split(m, n, (int)ktiles, -1, dtype == GMD_DT_MXFP8).schedule) return false;  // runs split along K
+  if (plan_split(m, n, (int)ktiles, -1, dtype == GMD_DT_MXFP8).schedule) return true;  // split along K: the reduce kernel sums
   return m % BM == 0 && n % BN == 0 && ktiles >= 2 && ktiles % 2 == 0 && (dtype == GMD_DT_MXFP8 || tiles128 > persistent_grid());
 }
 

@@ -545,20 +545,25 @@ def test_soak_holds_every_launch_against_the_first(diag):
     assert g["checked_in_kernel"] == g["launches"] and 0 < g["checked_in_memory"] <= g["launches"] // 8 + 1, g
     small = diag.gemm_stress("bf16", 2048, 2048, 2048, seconds=0.3)   # the small-tile kernel has no summing epilogue
     assert small["verified"] == 1 and small["checked_in_kernel"] == 0 and small["checked_in_memory"] > 0, small
+    # shapes that run split along K: the kernel that adds the ranges up sums what it stores (small tiles, large tiles, MX-fp8)
+    for dtype, shape in (("bf16", (1024, 1024, 4096)), ("bf16", (2048, 2048, 16384)), ("mxfp8", (2048, 2048, 16384))):
+        assert diag.gemm_plan(dtype, *shape)[0] in (9, 10)
+        g = diag.gemm_stress(dtype, *shape, seconds=0.3)
+        assert g["verified"] == 1 and g["sdc_mismatches"] == 0 and g["checked_in_kernel"] == g["launches"] > 0, (dtype, shape, g)
     code = ("import json; from k8s_gpu_monitor_amd.ops import diag\n"
-            "try:\n    g = diag.gemm_stress('%s', 4096, 4096, 4096, seconds=0.5)\n    print(json.dumps({'ok': True, 'sdc': g['sdc_mismatches']}))\n"
+            "try:\n    g = diag.gemm_stress('%s', %d, %d, %d, seconds=0.5)\n    print(json.dumps({'ok': True, 'sdc': g['sdc_mismatches']}))\n"
             "except diag.DiagError as e:\n    print(json.dumps({'ok': False, 'msg': str(e)}))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for dtype in ("bf16", "fp8"):
+    for dtype, shape in (("bf16", (4096, 4096, 4096)), ("fp8", (4096, 4096, 4096)), ("bf16", (2048, 2048, 16384)), ("fp8", (1024, 1024, 8192))):
         for env, caught in (({"GPUMON_GEMM_INJECT_AT": "3"}, True), ({"GPUMON_GEMM_INJECT_AT": "3", "GPUMON_GEMM_NO_REGSUM": "1"}, False),
                             ({"GPUMON_GEMM_INJECT_AT": "16", "GPUMON_GEMM_NO_REGSUM": "1"}, True)):
-            r = subprocess.run([sys.executable, "-c", code % dtype], capture_output=True, text=True, timeout=120,
+            r = subprocess.run([sys.executable, "-c", code % ((dtype,) + shape)], capture_output=True, text=True, timeout=120,
                                env=dict(os.environ, PYTHONPATH=root, **env))
             assert r.returncode == 0, r.stderr[-400:]
             out = json.loads(r.stdout.strip().splitlines()[-1])
             # launch 3 lies between two passes over C (launches 0 and 8): only the in-kernel sum sees it; launch 16 is
             # followed by a pass over C and is seen either way
-            assert out["ok"] == (not caught), (dtype, env, out)
+            assert out["ok"] == (not caught), (dtype, shape, env, out)
             if caught:
                 assert "differ from the first" in out["msg"], out
 
