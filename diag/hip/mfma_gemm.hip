@@ -1953,7 +1953,7 @@ __device__ __forceinline__ unsigned s128_store_blocks(const f32x4 (&acc)[4], __b
   return sum;
 }
 
-template <int DT, int NSTAGE = kS128Stages, bool SPLIT = false>
+template <int DT, int NSTAGE = kS128Stages, bool SPLIT = false, bool SUM = false>  // SUM: the soak's instantiation (g_gemm_reg_sum)
 __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args args) {
   const int region = !SPLIT && (int)blockIdx.x >= args.tiles0 ? 1 : 0;  // workgroup-uniform
   const char* __restrict__ A = args.r[region].a;
@@ -2139,8 +2139,10 @@ __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args arg
   }
   const int row0 = tm * kS128 + wr * 64 + fr;
   const int col0 = tn * kS128 + wc * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+  unsigned sum = 0;
 #pragma unroll
-  for (int mb = 0; mb < 4; mb++) s128_store_blocks(acc[mb], C, M, N, ldc, row0 + mb * 16, col0);
+  for (int mb = 0; mb < 4; mb++) sum += s128_store_blocks(acc[mb], C, M, N, ldc, row0 + mb * 16, col0);
+  if constexpr (SUM) reg_sum_add(sum, lane);
 }
 
 // Second half of a GEMM split along K: workgroup (tile, w) adds up, for wave w of the tile, the accumulators that the
@@ -2398,9 +2400,12 @@ int launch_gemm_t(const GemmArgs& g) {
       GMD_HIP(hipGetDevice(&dev));
       if (attr_dev != dev) {
         GMD_HIP(hipFuncSetAttribute((const void*)gemm_s128_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, kS128LdsBytes));
+        GMD_HIP(hipFuncSetAttribute((const void*)gemm_s128_kernel<DT, kS128Stages, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kS128LdsBytes));
         attr_dev = dev;
       }
-      gemm_s128_kernel<DT><<<grid_s, kS128Threads, kS128LdsBytes, g.st>>>(a);
+      if (g.reg_sum) gemm_s128_kernel<DT, kS128Stages, false, true><<<grid_s, kS128Threads, kS128LdsBytes, g.st>>>(a);
+      else gemm_s128_kernel<DT><<<grid_s, kS128Threads, kS128LdsBytes, g.st>>>(a);
       GMD_HIP(hipGetLastError());
       return GMD_OK;
     };
@@ -2631,14 +2636,15 @@ int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles) {
 }
 
 // Shapes a launch of which sums what it stores: what the default schedule runs as whole 256 x 256 tiles over K-tile
-// pairs on the four-wave kernel (not the unsplit small-tile kernel, not the general instantiation), and what it runs
-// split along K (the kernel that adds the ranges up sums); with no schedule asked for.
+// pairs on the four-wave kernel (not the general instantiation, nor a matrix cut into large tiles and strips of small
+// ones), on small tiles alone, or split along K (the kernel that adds the ranges up sums); with no schedule asked for.
 static bool reg_sum_shape(int dtype, int m, int n, int k) {
   const int asked = gemm_variant();
   if (asked >= 0 && asked <= kVariantMax) return false;
   const size_t ktiles = (size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB;
   const int tiles128 = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
   if (plan_split(m, n, (int)ktiles, -1, dtype == GMD_DT_MXFP8).schedule) return true;  // split along K: the reduce kernel sums
+  if (dtype != GMD_DT_MXFP8 && tiles128 <= persistent_grid()) return true;               // small tiles, unsplit
   return m % BM == 0 && n % BN == 0 && ktiles >= 2 && ktiles % 2 == 0 && (dtype == GMD_DT_MXFP8 || tiles128 > persistent_grid());
 }
 
