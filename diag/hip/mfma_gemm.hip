@@ -231,6 +231,7 @@ __device__ __forceinline__ void store_acc_rows_edge(const f32x4 (&acc)[8][8], __
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   const int col = col0 + fr * 8;
+  unsigned sum = 0;  // EPI = 3: of the words stored, as in store_acc_rows
 #pragma unroll
   for (int mb = 0; mb < 8; mb++) {
 #pragma unroll
@@ -242,11 +243,13 @@ __device__ __forceinline__ void store_acc_rows_edge(const f32x4 (&acc)[8][8], __
         o[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{acc[mb][2 * h][r], acc[mb][2 * h + 1][r]}, bf16x2));
       if (row < M && col < N) {  // N is a multiple of 8: a lane's eight columns are inside or outside together
         u32x4* dst = (u32x4*)(C + (size_t)row * ldc + col);
-        if constexpr (EPI == 1) __builtin_nontemporal_store(o, dst);
+        if constexpr (EPI == 1 || EPI == 3) __builtin_nontemporal_store(o, dst);
         else *dst = o;
+        if constexpr (EPI == 3) sum += (o[0] + o[1]) + (o[2] + o[3]);
       }
     }
   }
+  if constexpr (EPI == 3) reg_sum_add(sum, fq * 16 + fr);
 }
 
 // Which range of K and which tile a workgroup of a split GEMM takes (grid = tiles x splits).  The dispatcher deals
@@ -2472,14 +2475,19 @@ int launch_gemm_t(const GemmArgs& g) {
       }
     }
   }
+  if (g.reg_sum && (!full_tiles || !pairs)) {  // the soak at a ragged shape: the general instantiation with the summing epilogue
+    // (unscaled fp8 is on the K=128 instruction here: the sum is taken only with the schedule left to the launcher)
+    if constexpr (kFp8) return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 3, false, true, true>, grid, kThreadsW4, kLdsBytes, g);
+    else return launch_lds(gemm_w4_kernel<DT, 0, 3, false, true>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
+  }
   if (!full_tiles || (!pairs && gemm_variant() != 0)) {
     if (fp8_wide)
       return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 1, false, true, true>, grid, kThreadsW4, kLdsBytes, g);
     return launch_lds(gemm_w4_kernel<DT, 0, 1, false, true>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
   }
   if (g.reg_sum) {  // the soak: the default kernel of the data type with the summing epilogue (whole tiles, K-tile pairs)
-    if (fp8_wide) return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 3, false, false, true>, grid, kThreadsW4, kLdsBytes, g);
-    return launch_lds(gemm_w4_kernel<DT, 0, 3>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
+    if constexpr (kFp8) return launch_lds(gemm_w4_kernel<GMD_DT_MXFP8, 0, 3, false, false, true>, grid, kThreadsW4, kLdsBytes, g);
+    else return launch_lds(gemm_w4_kernel<DT, 0, 3>, grid, kThreadsW4, kLdsBytes + (kMx ? kScaleRingBytes : 0), g);
   }
 #define GMD_LAUNCH(KFN, GRID, THREADS) return launch_lds(KFN, GRID, THREADS, kLdsBytes, g)
 #ifdef GMD_GEMM_ABLATE
@@ -2635,17 +2643,12 @@ int gmd_gemm_read_timeline(unsigned long long* out, int n_tiles) {
 #endif
 }
 
-// Shapes a launch of which sums what it stores: what the default schedule runs as whole 256 x 256 tiles over K-tile
-// pairs on the four-wave kernel (not the general instantiation, nor a matrix cut into large tiles and strips of small
-// ones), on small tiles alone, or split along K (the kernel that adds the ranges up sums); with no schedule asked for.
-static bool reg_sum_shape(int dtype, int m, int n, int k) {
+// Whether a launch sums what it stores (the soak's check of every launch): with the schedule left to the launcher every
+// path has such an instantiation (large tiles, the general instantiation, small tiles, strips of small tiles next to
+// large ones, and the kernels that add up a GEMM split along K); a schedule asked for by number runs as it is.
+static bool reg_sum_shape(int, int, int, int) {
   const int asked = gemm_variant();
-  if (asked >= 0 && asked <= kVariantMax) return false;
-  const size_t ktiles = (size_t)k * (dtype == GMD_DT_BF16 ? 2 : 1) / BKB;
-  const int tiles128 = ((m + kS128 - 1) / kS128) * ((n + kS128 - 1) / kS128);
-  if (plan_split(m, n, (int)ktiles, -1, dtype == GMD_DT_MXFP8).schedule) return true;  // split along K: the reduce kernel sums
-  if (dtype != GMD_DT_MXFP8 && tiles128 <= persistent_grid()) return true;               // small tiles, unsplit
-  return m % BM == 0 && n % BN == 0 && ktiles >= 2 && ktiles % 2 == 0 && (dtype == GMD_DT_MXFP8 || tiles128 > persistent_grid());
+  return asked < 0 || asked > kVariantMax;
 }
 
 static int gemm_launch_checked(int dtype, const void* a, const void* b, const void* sa, const void* sb, void* c, int m, int n, int k,

@@ -20,10 +20,10 @@ def test_no_accumulator_is_read_before_the_matrix_pipe_is_drained():
                        timeout=300)
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert r.returncode == 0, r.stdout + r.stderr
-    # three data types x (per tile, general, stream), the per-tile kernels once more with the summing epilogue of the soak,
-    # and all three with the epilogue of a GEMM split along K (fp32 accumulators to the workspace)
-    assert len(lines) == 19 and all(ln.endswith(": ok") for ln in lines), r.stdout
-    assert sum(", 0, 3, false, false" in ln for ln in lines) == 4, r.stdout
+    # three data types x (per tile, general, stream), the per-tile and the general kernels once more with the summing epilogue
+    # of the soak, and all three with the epilogue of a GEMM split along K (fp32 accumulators to the workspace)
+    assert len(lines) == 21 and all(ln.endswith(": ok") for ln in lines), r.stdout
+    assert sum(", 0, 3, false, false" in ln for ln in lines) == 3 and sum(", 0, 3, false, true" in ln for ln in lines) == 3, r.stdout
     assert sum(", 0, 4, false, false" in ln for ln in lines) == 3, r.stdout
 
 

@@ -545,8 +545,11 @@ def test_soak_holds_every_launch_against_the_first(diag):
     assert g["checked_in_kernel"] == g["launches"] and 0 < g["checked_in_memory"] <= g["launches"] // 8 + 1, g
     small = diag.gemm_stress("bf16", 2048, 2048, 2048, seconds=0.3)   # the small-tile kernel sums as well
     assert small["verified"] == 1 and small["checked_in_kernel"] == small["launches"] and small["checked_in_memory"] > 0, small
-    ragged = diag.gemm_stress("bf16", 8200, 8200, 8192, seconds=0.3)  # large tiles and strips of small ones: the pass over C only
-    assert ragged["verified"] == 1 and ragged["checked_in_kernel"] == 0 and ragged["checked_in_memory"] > 0, ragged
+    # large tiles and strips of small ones; the general instantiation (partial tiles, an odd number of K-tiles), MX-fp8 too
+    for dtype, shape in (("bf16", (8200, 8200, 8192)), ("bf16", (4000, 4104, 4160)), ("fp8", (4096, 4096, 4096 + 128)),
+                         ("mxfp8", (4096, 4096, 4096 + 128))):
+        g = diag.gemm_stress(dtype, *shape, seconds=0.3)
+        assert g["verified"] == 1 and g["sdc_mismatches"] == 0 and g["checked_in_kernel"] == g["launches"] > 0, (dtype, shape, g)
     # shapes that run split along K: the kernel that adds the ranges up sums what it stores (small tiles, large tiles, MX-fp8)
     for dtype, shape in (("bf16", (1024, 1024, 4096)), ("bf16", (2048, 2048, 16384)), ("mxfp8", (2048, 2048, 16384))):
         assert diag.gemm_plan(dtype, *shape)[0] in (9, 10)
@@ -557,7 +560,7 @@ def test_soak_holds_every_launch_against_the_first(diag):
             "except diag.DiagError as e:\n    print(json.dumps({'ok': False, 'msg': str(e)}))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for dtype, shape in (("bf16", (4096, 4096, 4096)), ("fp8", (4096, 4096, 4096)), ("bf16", (2048, 2048, 16384)), ("fp8", (1024, 1024, 8192)),
-                         ("bf16", (1000, 520, 640))):
+                         ("bf16", (1000, 520, 640)), ("bf16", (4000, 4104, 4160))):
         for env, caught in (({"GPUMON_GEMM_INJECT_AT": "3"}, True), ({"GPUMON_GEMM_INJECT_AT": "3", "GPUMON_GEMM_NO_REGSUM": "1"}, False),
                             ({"GPUMON_GEMM_INJECT_AT": "16", "GPUMON_GEMM_NO_REGSUM": "1"}, True)):
             r = subprocess.run([sys.executable, "-c", code % ((dtype,) + shape)], capture_output=True, text=True, timeout=120,
