@@ -172,14 +172,19 @@ __device__ __forceinline__ void store_acc(const f32x4 (&acc)[8][NBLK], __bf16* _
 // over the wave, then one atomic per wave into g_gemm_reg_sum.  Identical operands give an identical sum launch after
 // launch, so the host can hold EVERY launch of a soak against the first without a pass over C in memory; what that
 // cannot see, a store or a memory cell that corrupts, the checksum pass over C (every Nth launch) still covers.
-__device__ unsigned long long g_gemm_reg_sum;
+// The sum lives in kRegSumSlots words, one per 64-byte line, and a wave adds to the slot of its workgroup: atomics to ONE
+// address are served one after the other, and the 2048 waves of a reduce kernel, all done at the same moment, took 20 us
+// over theirs (2048 x 2048 x 16384 split in four: 128 -> 108 us per launch in the soak).
+constexpr int kRegSumSlots = 64;
+__device__ unsigned long long g_gemm_reg_sum[kRegSumSlots * 8];
+__device__ __forceinline__ unsigned long long* reg_sum_slot() { return &g_gemm_reg_sum[(blockIdx.x % kRegSumSlots) * 8]; }
 
 // One atomic per wave into g_gemm_reg_sum (the kernels that add the ranges of a split GEMM up; store_acc_rows has its own).
 __device__ __forceinline__ void reg_sum_add(unsigned sum, int lane) {
   unsigned long long wide = sum;
 #pragma unroll
   for (int off = 32; off; off >>= 1) wide += __shfl_xor(wide, off, 64);
-  if (lane == 0) atomicAdd(&g_gemm_reg_sum, wide);
+  if (lane == 0) atomicAdd(reg_sum_slot(), wide);
 }
 
 template <int EPI, bool PACE = false>
@@ -209,7 +214,7 @@ __device__ __forceinline__ void store_acc_rows(const f32x4 (&acc)[8][8], __bf16*
     unsigned long long wide = sum;
 #pragma unroll
     for (int off = 32; off; off >>= 1) wide += __shfl_xor(wide, off, 64);
-    if (fr == 0 && fq == 0) atomicAdd(&g_gemm_reg_sum, wide);
+    if (fr == 0 && fq == 0) atomicAdd(reg_sum_slot(), wide);
   }
 }
 
@@ -217,10 +222,17 @@ __device__ __forceinline__ void store_acc_rows(const f32x4 (&acc)[8][8], __bf16*
 __global__ void flip_bits_kernel(unsigned* p, unsigned mask) { *p ^= mask; }
 
 // Moves the soak's running sum to where the host reads it (pinned host memory) and starts the next batch from zero.
+// One wave, a slot per lane.
 __global__ void reg_sum_harvest_kernel(unsigned long long* dst) {
-  *dst = g_gemm_reg_sum;
-  g_gemm_reg_sum = 0;
-  __threadfence_system();
+  static_assert(kRegSumSlots == 64, "one slot per lane");
+  unsigned long long sum = g_gemm_reg_sum[threadIdx.x * 8];
+  g_gemm_reg_sum[threadIdx.x * 8] = 0;
+#pragma unroll
+  for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (threadIdx.x == 0) {
+    *dst = sum;
+    __threadfence_system();
+  }
 }
 
 // store_acc_rows for a tile that reaches beyond M or N: the same stores, each behind its own bounds test.
@@ -2825,9 +2837,9 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
   if (reg) {
     GMD_HIP(hipHostMalloc((void**)&harvest.p, (kMarkRing + 2) * sizeof(unsigned long long), hipHostMallocDefault));
     GMD_HIP(hipHostGetDevicePointer((void**)&harvest_dev, harvest.p, 0));
-    reg_sum_harvest_kernel<<<1, 1, 0, rig.gemm>>>(harvest_dev + kMarkRing + 1);  // start from zero
+    reg_sum_harvest_kernel<<<1, kRegSumSlots, 0, rig.gemm>>>(harvest_dev + kMarkRing + 1);  // start from zero
     if ((rc = gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, c.p, m, n, k, rig.gemm, true))) return rc;
-    reg_sum_harvest_kernel<<<1, 1, 0, rig.gemm>>>(harvest_dev + kMarkRing + 1);
+    reg_sum_harvest_kernel<<<1, kRegSumSlots, 0, rig.gemm>>>(harvest_dev + kMarkRing + 1);
     GMD_HIP(hipGetLastError());
     GMD_HIP(hipStreamSynchronize(rig.gemm));
     reg_ref = harvest.p[kMarkRing + 1];
@@ -2888,7 +2900,7 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
       }
     }
     batches++;
-    if (reg) reg_sum_harvest_kernel<<<1, 1, 0, rig.gemm>>>(harvest_dev + batches % (kMarkRing + 1));
+    if (reg) reg_sum_harvest_kernel<<<1, kRegSumSlots, 0, rig.gemm>>>(harvest_dev + batches % (kMarkRing + 1));
     GMD_HIP(hipEventRecord(rig.mark[batches % (kMarkRing + 1)], rig.gemm));
     // at most kRing - 1 batches in flight: the slot that the next mark takes has been read by then
     while (batches - settled >= (uint64_t)kMarkRing - 1) {
