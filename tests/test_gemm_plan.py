@@ -100,3 +100,38 @@ def test_schedules_asked_for_split_as_far_as_they_can():
         diag.gemm_set_split(1)
     with pytest.raises(diag.DiagError):
         diag.gemm_set_split(9)
+
+
+def test_any_shape_gets_a_plan_the_kernels_can_run():
+    """Random shapes and schedules: whatever the planner answers must satisfy what the kernels assume (these are the
+    conditions under which their indexing stays inside the operands and the workspace)."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=400, deadline=None)
+    @given(st.sampled_from(["bf16", "fp8", "mxfp8"]), st.integers(1, 1100), st.integers(1, 1100), st.integers(1, 1200),
+           st.sampled_from([-1, 9, 10]), st.sampled_from([0, 0, 2, 3, 5, 8]))
+    def check(dtype, m8, n8, kt, variant, asked_splits):
+        step = 256 if dtype == "mxfp8" else 8
+        m, n, k = m8 * step, n8 * step, kt * (64 if dtype == "bf16" else 128)
+        diag.gemm_set_variant(variant)
+        diag.gemm_set_split(asked_splits)
+        schedule, ranges = diag.gemm_plan(dtype, m, n, k)
+        assert schedule in (0, 9, 10) and (schedule == 0) == (ranges == 1)
+        if dtype == "mxfp8":
+            assert schedule != 9
+        if variant in (9, 10):
+            assert schedule in (0, variant)
+            if schedule and asked_splits:
+                assert ranges <= asked_splits
+        if schedule == 9:
+            tiles = -(-m // 128) * -(-n // 128)
+            per = -(-kt // ranges)
+            assert 2 <= ranges <= 8 and tiles * ranges <= CUS and per >= 1 and (ranges - 1) * per < kt
+        if schedule == 10:
+            per = (-(-kt // ranges) + 1) & ~1
+            assert m % 256 == 0 and n % 256 == 0 and kt % 2 == 0 and kt >= 4
+            assert 2 <= ranges <= 8 and (m // 256) * (n // 256) * ranges <= CUS
+            assert per >= 2 and (ranges - 1) * per < kt and (kt - (ranges - 1) * per) % 2 == 0
+
+    check()
