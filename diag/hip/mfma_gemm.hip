@@ -2320,6 +2320,15 @@ SplitPlan plan_split(int m, int n, int ktiles, int asked, bool large_only = fals
   return plan;
 }
 
+// What the split kernels' indexing rests on, checked once more at the launch: every range has K-tiles (whole pairs on large
+// tiles), and every workgroup has its slab in the workspace.  A plan that fails this is not launched (the GEMM runs unsplit).
+bool split_plan_fits(const SplitPlan& p, int tiles, int ktiles) {
+  if (p.splits < 2 || p.per < 1 || tiles < 1 || (long long)tiles * p.splits > kSplitMaxSlabs) return false;
+  if ((long long)(p.splits - 1) * p.per >= ktiles || (long long)p.splits * p.per < ktiles) return false;
+  if (p.schedule == 10) return (p.per & 1) == 0 && (ktiles & 1) == 0;
+  return p.schedule == 9;
+}
+
 // The workspace of the split: one per device and stream (launches on one stream follow one another; two streams may
 // run two split GEMMs at once), allocated at first use and kept for the life of the process.
 float* split_workspace(hipStream_t st) {
@@ -2384,7 +2393,7 @@ int launch_gemm_t(const GemmArgs& g) {
     const bool automatic = asked < 0 || asked > kVariantMax;
     if ((asked == 10 || automatic) && !g.ldc && full_tiles) {
       const SplitPlan plan = plan_split(g.m, g.n, (int)ktiles, automatic ? -1 : 10, true);
-      float* const work = plan.schedule == 10 ? split_workspace(g.st) : nullptr;
+      float* const work = plan.schedule == 10 && split_plan_fits(plan, grid, (int)ktiles) ? split_workspace(g.st) : nullptr;
       if (work) {
         GemmArgs part = g;
         part.c = work;
@@ -2429,7 +2438,9 @@ int launch_gemm_t(const GemmArgs& g) {
     // Split along K where the model (plan_split) has it ahead, or where it is asked for.
     if ((asked == 9 || asked == 10 || automatic) && !g.ldc) {
       const SplitPlan plan = plan_split(g.m, g.n, (int)ktiles, automatic ? -1 : asked);
-      float* const work = plan.schedule ? split_workspace(g.st) : nullptr;
+      const bool fits = plan.schedule && split_plan_fits(plan, plan.schedule == 10 ? grid : tiles128(g.m, g.n), (int)ktiles) &&
+                        (plan.schedule != 10 || (full_tiles && pairs));
+      float* const work = fits ? split_workspace(g.st) : nullptr;
       if (work && plan.schedule == 10) {
         GemmArgs part = g;
         part.c = work;
