@@ -170,7 +170,7 @@ def test_memtest_march_scrub_and_locatable_errors(diag):
     assert r["log"][0]["device_address"] == r["log"][1]["device_address"]
     clean = diag.memtest(bytes=8 << 30, patterns=diag.PATTERNS["random"], march=True)
     assert clean["errors"] == 0 and clean["march_passes"] == 1 and clean["scrubbed"] == 1
-    assert clean["march_tbps"] > 4.5, clean   # bytes read + written per second
+    assert clean["march_tbps"] > 5.5, clean   # bytes read + written per second
     # the scrub costs next to nothing at this size
     assert clean["write_tbps"] > 5.3 and clean["verify_tbps"] > 5.0, clean
 
