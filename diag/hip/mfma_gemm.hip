@@ -1937,7 +1937,8 @@ struct S128Args {
 };
 
 // A wave's accumulators in the split workspace: one 16-byte word per lane and 16 x 16 block, so that a wave's store or
-// load of a block is one contiguous KiB.  Slab (split, tile, wave) holds 16 blocks (mb * 4 + nb).
+// load of a block is one contiguous KiB.  Slab (split, tile, wave) holds 16 blocks (mb * 4 + nb).  Plain stores and
+// loads: the partial sums are read back within microseconds, and non-temporal ones were 1 to 6 % slower per GEMM.
 constexpr size_t kS128SlabFloats = 16 * 64 * 4;  // per wave
 __device__ __forceinline__ f32x4* s128_slab(float* work, int split, int tiles, int tile, int wave) {
   return (f32x4*)(work + (((size_t)split * tiles + tile) * 4 + wave) * kS128SlabFloats);
