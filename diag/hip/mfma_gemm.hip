@@ -269,13 +269,14 @@ __device__ __forceinline__ void store_acc_rows_edge(const f32x4 (&acc)[8][8], __
 // tiles of the grouped walk (for 64 tiles in 4 ranges: XCD x takes range x % 4 of tiles 32 (x / 4) ...), so that its 32
 // workgroups share operand panels in its L2; with every range of a tile on the same XCD an XCD would fetch `splits`
 // times as many panels per step (2048 x 2048 x 16384 in 4: 105 -> 75 us).  *tile is then the walk's index itself (true),
-// otherwise the block id to be spread over the XCDs as in an unsplit launch (false).  Short ranges (under 32 K-tiles,
-// 4 KiB of a row) stay with that: an XCD that reads one short window of every operand row was measured slower
-// (1024 x 1024 x 4096 in 4 ranges of 16: 19.5 -> 21.0 us; ranges of 32 and more: level or ahead, 33.4 -> 29.7 us at
-// 1024 x 512 x 16384 in 8).
-__device__ __forceinline__ bool split_of_block(int block, int splits, int tiles, int per, int* split, int* tile) {
+// otherwise the block id to be spread over the XCDs as in an unsplit launch (false).  Ranges under min_per K-tiles stay
+// with that.  Small tiles, min_per = 32 (4 KiB of a row): an XCD that reads one short window of every operand row was
+// measured slower (1024 x 1024 x 4096 in 4 ranges of 16: 19.5 -> 21.0 us; ranges of 32 and more: level or ahead,
+// 33.4 -> 29.7 us at 1024 x 512 x 16384 in 8).  Large tiles, min_per = 8: never slower, 39.6 -> 36.9 us at
+// 1536 x 1024 x 8192 in 8 ranges of 16.
+__device__ __forceinline__ bool split_of_block(int block, int splits, int tiles, int per, int min_per, int* split, int* tile) {
   const int groups = splits <= 8 ? 8 / splits : 0;  // XCDs per range of K
-  if (per >= 32 && groups * splits == 8 && tiles % groups == 0) {
+  if (per >= min_per && groups * splits == 8 && tiles % groups == 0) {
     const int x = block & 7, per_xcd = tiles / groups;
     *split = x % splits;
     *tile = (x / splits) * per_xcd + (block >> 3);
@@ -1127,7 +1128,7 @@ __global__ __launch_bounds__(kThreadsW4) void gemm_w4_kernel(const char* __restr
   const int nunits = STREAM || kSplit ? tiles_m * tiles_n : (int)gridDim.x;
   int bid = (int)blockIdx.x, split = 0;
   bool split_by_xcd = false;
-  if constexpr (kSplit) split_by_xcd = split_of_block((int)blockIdx.x, (int)gridDim.x / nunits, nunits, ldc, &split, &bid);
+  if constexpr (kSplit) split_by_xcd = split_of_block((int)blockIdx.x, (int)gridDim.x / nunits, nunits, ldc, 8, &split, &bid);
   const int kt_first = kSplit ? split * ldc : 0;
   const int kcount = kSplit ? min(ldc, (int)(row_bytes / BKB) - kt_first) : (int)(row_bytes / BKB);  // K-tiles this workgroup walks
   const int xcd = bid & 7, q8 = nunits >> 3, r8n = nunits & 7;
@@ -1989,7 +1990,7 @@ __global__ __launch_bounds__(kS128Threads, 1) void gemm_s128_kernel(S128Args arg
   const int nwg = region ? (int)gridDim.x - args.tiles0 : args.tiles0;
   int split = 0, bid = (int)blockIdx.x - (region ? args.tiles0 : 0);
   bool split_by_xcd = false;
-  if constexpr (SPLIT) split_by_xcd = split_of_block((int)blockIdx.x, (int)gridDim.x / args.tiles0, args.tiles0, args.kt_per_split, &split, &bid);
+  if constexpr (SPLIT) split_by_xcd = split_of_block((int)blockIdx.x, (int)gridDim.x / args.tiles0, args.tiles0, args.kt_per_split, 32, &split, &bid);
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int wgid = split_by_xcd ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   int tm, tn;
