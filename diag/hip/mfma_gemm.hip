@@ -1680,6 +1680,7 @@ __device__ __forceinline__ unsigned long long checksum_word(csum_u32x4 v) {
 
 // Runs between the launches of a soak, so it is written to take HBM time and no more: four independent streaming
 // 16-byte loads in flight per lane (C was stored non-temporally and comes from memory, not from a cache).
+constexpr int kChecksumSlots = 8;  // words of a result, 64 bytes apart
 __global__ __launch_bounds__(256) void checksum_kernel(const uint4* __restrict__ c4, uint64_t n16, unsigned long long* out) {
   const csum_u32x4* c = reinterpret_cast<const csum_u32x4*>(c4);
   unsigned long long s = 0;
@@ -1692,13 +1693,17 @@ __global__ __launch_bounds__(256) void checksum_kernel(const uint4* __restrict__
   }
   for (; i < n16; i += stride) s += checksum_word(__builtin_nontemporal_load(c + i));
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  // One atomic per workgroup: thousands of 64-bit atomics on the one result word are served one after the other
-  // by a single L2 channel and took four times as long as the reads themselves when every wave issued its own.
+  // One atomic per workgroup, into one of kChecksumSlots words of a line each (the host adds them up): thousands of
+  // 64-bit atomics on one result word are served one after the other by a single L2 channel and took four times as long
+  // as the reads themselves when every wave issued its own; a thousand workgroups' still took 10 us of a 31 us pass.
   __shared__ unsigned long long part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) atomicAdd(out + (blockIdx.x % kChecksumSlots) * 8, part[0] + part[1] + part[2] + part[3]);
 }
+// Workgroups of a checksum pass over n16 16-byte words: sixteen loads per lane at least (a small C does not pay for a
+// thousand workgroups' launch and atomics), at most four workgroups per CU.
+unsigned checksum_grid(uint64_t n16) { return (unsigned)std::min<uint64_t>(1024, std::max<uint64_t>(32, n16 / (256 * 16))); }
 
 // ---- operand fill: counter-based uniform [-1, 1) ------------------------------
 __device__ __forceinline__ uint32_t hash32(uint64_t x) {
@@ -2756,7 +2761,7 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
   const int kWindow = 1 << 13;
   const int kSamples = 4096;
   if ((rc = a.alloc((size_t)m * k * esz)) || (rc = b.alloc((size_t)n * k * esz)) || (rc = c.alloc((size_t)m * n * 2)) ||
-      (rc = sums.alloc(sizeof(unsigned long long) * kWindow)) || (rc = refs.alloc(sizeof(float) * 2 * kSamples)))
+      (rc = sums.alloc(sizeof(unsigned long long) * kWindow * kChecksumSlots * 8)) || (rc = refs.alloc(sizeof(float) * 2 * kSamples)))
     return rc;
   if (fp8) {
     fill_fp8_kernel<<<2048, 256>>>((uint8_t*)a.p, (uint64_t)m * k, 1);
@@ -2774,7 +2779,7 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
     if ((rc = gmd_mx_pack_scales(sa_nat.p, sa_pk.p, m, k, nullptr)) || (rc = gmd_mx_pack_scales(sb_nat.p, sb_pk.p, n, k, nullptr))) return rc;
   }
   auto launch = [&]() { return gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, c.p, m, n, k, nullptr); };
-  GMD_HIP(hipMemset(sums.p, 0, sizeof(unsigned long long) * kWindow));
+  GMD_HIP(hipMemset(sums.p, 0, sizeof(unsigned long long) * kWindow * kChecksumSlots * 8));
   GMD_HIP(hipGetLastError());
   if ((rc = launch())) return rc;  // warm-up; also the launch that is checked against the reference
   GMD_HIP(hipDeviceSynchronize());
@@ -2867,15 +2872,19 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
   uint64_t launches = 0, in_window = 0, batches = 0;
   unsigned long long ref_sum = 0;
   bool have_ref = false;
-  std::vector<unsigned long long> h(kWindow);
+  constexpr size_t kSumWords = kChecksumSlots * 8;  // words per checksum in `sums`
+  std::vector<unsigned long long> h((size_t)kWindow * kSumWords);
   auto drain = [&]() -> int {  // both streams idle: compare the window against the first checksum, clear it
     if (!verify || !in_window) return GMD_OK;
     GMD_HIP(hipStreamSynchronize(rig.gemm));
-    GMD_HIP(hipMemcpy(h.data(), sums.p, in_window * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (!have_ref) ref_sum = h[0], have_ref = true;
-    for (uint64_t i = 0; i < in_window; i++)
-      if (h[i] != ref_sum) out->sdc_mismatches++;
-    GMD_HIP(hipMemset(sums.p, 0, in_window * sizeof(unsigned long long)));
+    GMD_HIP(hipMemcpy(h.data(), sums.p, in_window * kSumWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < in_window; i++) {
+      unsigned long long sum = 0;
+      for (int slot = 0; slot < kChecksumSlots; slot++) sum += h[i * kSumWords + slot * 8];
+      if (!have_ref) ref_sum = sum, have_ref = true;
+      if (sum != ref_sum) out->sdc_mismatches++;
+    }
+    GMD_HIP(hipMemset(sums.p, 0, in_window * kSumWords * sizeof(unsigned long long)));
     in_window = 0;
     return GMD_OK;
   };
@@ -2907,7 +2916,7 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
         flip_bits_kernel<<<1, 1, 0, rig.gemm>>>((unsigned*)a.p, inject_mask);
       if ((rc = gemm_launch_checked(dtype, a.p, b.p, sa_pk.p, sb_pk.p, c.p, m, n, k, rig.gemm, reg))) return rc;
       if (verify && launches % check_every == 0) {
-        checksum_kernel<<<1024, 256, 0, rig.gemm>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + in_window);
+        checksum_kernel<<<checksum_grid(n16), 256, 0, rig.gemm>>>((const uint4*)c.p, n16, (unsigned long long*)sums.p + in_window * kSumWords);
         in_window++;
         out->checked_in_memory++;
       }
