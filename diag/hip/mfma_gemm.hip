@@ -2888,7 +2888,9 @@ int gmd_gemm_stress_run(const gmd_gemm_stress_config_t* cfg, gmd_mfma_result_t* 
     in_window = 0;
     return GMD_OK;
   };
-  const int batch = 8;
+  // Launches per batch (one harvest of the running sum, one mark): eight of the large ones; a small GEMM's launches are
+  // over in tens of microseconds, and the harvest kernel's four should stay a fraction of a percent of a batch.
+  const int batch = flops < 2e11 ? 32 : 8;
   // mark[b % (kRing + 1)] closes batch b; batch b's time is the distance between marks b-1 and b.
   auto settle = [&](uint64_t b) -> int {
     hipEvent_t e1 = rig.mark[b % (kMarkRing + 1)], e0 = rig.mark[(b + kMarkRing) % (kMarkRing + 1)];
