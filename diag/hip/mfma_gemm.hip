@@ -2260,7 +2260,7 @@ int launch_lds(gemm_fn_t kfn, int grid, int threads, int lds_bytes, const GemmAr
 // scripts/gpu_gemm_split_sweep.py (profiles/gemm_split_sweep.json; bf16 and fp8 cost the same per 128-byte K-tile):
 //   a K-tile costs a workgroup 0.475 us on small tiles and 0.9 us on large ones, more with more of the chip busy (the
 //   clock under the power cap, and the L2); a launch costs 4 to 6 us before its first and after its last K-tile; the
-//   partial sums cost 0.29 us per MiB (written, then read) and the second launch 2 to 4 us.
+//   partial sums cost 0.29 us per MiB (written, then read) and the second launch 2 to 3.3 us.
 // A split is taken when the model has it 3 % ahead of the unsplit launch.
 constexpr int kSplitMaxSlabs = 256;  // workgroups of a split launch (the workspace holds 256 KiB for each)
 constexpr int kSplitMax = 8;  // more was measured: 16 ranges are slower wherever they fit (512 x 512 x 8192: 18.2 -> 20.3 us)
@@ -2314,7 +2314,7 @@ SplitPlan plan_split(int m, int n, int ktiles, int asked, bool large_only = fals
     const SplitPlan p = small_split(t128, ktiles, s);
     if (!p.schedule || p.per < 4) continue;
     const int wgs = t128 * p.splits;
-    const double t = 8.0 + p.per * small_ktile(wgs) + 0.29 * wgs / 16.0;
+    const double t = 7.3 + p.per * small_ktile(wgs) + 0.29 * wgs / 16.0;
     if (t < best) best = t, plan = p;
   }
   for (int s = 2; s <= kSplitMax; s++) {
