@@ -1904,6 +1904,7 @@ double peak_flops_per_mfma(int dt) {
 // 6 = four waves of 128 x 128 as one stream per CU over its tiles (gemm_w4_kernel<.., STREAM>);
 // 7 = schedule 2 on the K=32 fp8 instruction (unscaled fp8 only, where 2 and 6 run the K=32 sums' products on the K=128
 // instruction, which adds them up in another order: an A/B reference; schedule 2 for the other data types).
+// 8 = 128 x 128 tiles (gemm_s128_kernel, below); 9 / 10 = small / large tiles split along K (plan_split, further below).
 // ---- (2f) small tiles for small problems -----------------------------------------
 //
 // The 256 x 256 tile of the pipelines above is what a large GEMM wants (one wave holds 128 x 128 of C and reads each
