@@ -672,6 +672,20 @@ def _run_diag(*args, timeout=110, env=None):
     return r.returncode, json.loads(r.stdout)
 
 
+def test_cli_soak_at_an_operators_shape_says_how_it_ran():
+    """`gpumon-diag gemm --m --n --k`: a shape off the table is graded on correctness alone; the report says into how many
+    ranges of K the launcher split it and that every launch was held against the first."""
+    rc, doc = _run_diag("gemm", "--dtype", "bf16,mxfp8", "--m", "2048", "--n", "2048", "--k", "16384", "--seconds", "1", "--no-telemetry")
+    assert rc == 0 and doc["result"] == "pass", doc["verdicts"]
+    for dtype in ("bf16", "mxfp8"):
+        g = doc["gemm_stress"][dtype]
+        assert g["split_k"] == 4 and g["expected_tflops"] is None and g["verified"] == 1 and g["sdc_mismatches"] == 0, g
+        assert g["checked_in_kernel"] == g["launches"] > 0 and g["checked_in_memory"] > 0, g
+    assert doc["gemm_stress"]["bf16"]["tflops"] > 900, doc["gemm_stress"]["bf16"]   # 1250-1300 measured; 914 unsplit
+    rc, doc = _run_diag("gemm", "--dtype", "bf16", "--m", "4096", "--n", "4096", "--k", "4096", "--seconds", "1", "--no-telemetry")
+    assert rc == 0 and doc["gemm_stress"]["bf16"]["split_k"] == 1, doc["gemm_stress"]
+
+
 def test_suites_grade_performance_against_the_expectation_table():
     """`run -r 2` holds every rate against the MI355X table: a healthy GPU passes, and the same GPU held against a table
     scaled by 1.5 (a seeded "slow" part) fails in the subsystem of the test that fell short: memory for the stream and
