@@ -304,6 +304,15 @@ class AmdSmiBackend : public Backend {
   void shutdown() override {
     pcie_run_ = false;
     if (pcie_thread_.joinable()) pcie_thread_.join();  // before mu_: the loop takes it once a round
+    {
+      std::vector<std::thread> checks;
+      {
+        std::lock_guard<std::mutex> cl(checks_mu_);
+        checks.swap(checks_);
+      }
+      for (auto& t : checks)
+        if (t.joinable()) t.join();  // none of them takes mu_; the library must outlive them
+    }
     std::lock_guard<std::mutex> l(mu_);
     if (!inited_) return;
     for (auto& d : devs_)
@@ -538,14 +547,17 @@ class AmdSmiBackend : public Backend {
 
   // One-time cross-check of the residency accumulators this backend reads from the metrics table against the
   // library's own violation report (amdsmi_get_violation_status).  That call sleeps 100 ms between two reads of
-  // its own, so it runs once, on a thread of its own, never in the sampler.
+  // its own, so it runs once, on a thread of its own, never in the sampler.  shutdown() joins the thread before it
+  // closes the library: left to itself (it was detached once) it could still be inside the library, asleep, when a
+  // short-lived caller shut the library down under it, and the heap paid for it a moment later.
   void check_violation_source(Dev& d) {
     if (!api_.amdsmi_get_violation_status) return;
     amdsmi_processor_handle h = d.h;
     const uint32_t index = d.st.index;
     auto fn_status = api_.amdsmi_get_violation_status;
     auto fn_metrics = api_.amdsmi_get_gpu_metrics_info;
-    std::thread([h, index, fn_status, fn_metrics] {
+    std::lock_guard<std::mutex> cl(checks_mu_);
+    checks_.emplace_back([h, index, fn_status, fn_metrics] {
       std::unique_ptr<amdsmi_violation_status_t> v(new amdsmi_violation_status_t);
       memset(v.get(), 0xff, sizeof *v);
       if (fn_status(h, v.get()) != AMDSMI_STATUS_SUCCESS) return;
@@ -559,8 +571,10 @@ class AmdSmiBackend : public Backend {
       else GM_LOGW("amdsmi: GPU %u residency accumulators differ from the library's violation report (counter %llu vs %llu, ppt %llu vs %llu)",
                    index, (unsigned long long)v->acc_counter, (unsigned long long)m.accumulation_counter,
                    (unsigned long long)v->acc_ppt_pwr, (unsigned long long)m.ppt_residency_acc);
-    }).detach();
+    });
   }
+  std::mutex checks_mu_;
+  std::vector<std::thread> checks_;  // one-time cross-checks that call the library from threads of their own
 
   // ---- PCIe TX / RX ---------------------------------------------------------------
   // amdsmi_get_gpu_pci_throughput measures for one second inside the driver, so it cannot sit in the sampler.  A

@@ -18,6 +18,9 @@
 // build: g++ -shared -fPIC -O1 -I/opt/rocm/include tests/stubs/amdsmi_stub.cc -o libamd_smi_stub.so
 #include <amd_smi/amdsmi.h>
 
+#include <unistd.h>
+
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,7 +63,27 @@ amdsmi_status_t amdsmi_init(uint64_t) {
   }
   return AMDSMI_STATUS_SUCCESS;
 }
-amdsmi_status_t amdsmi_shut_down(void) { return AMDSMI_STATUS_SUCCESS; }
+// A call that is still inside the library when the library is shut down is the caller's fault; the real library does not
+// say so, it goes on with freed state.  This one does: amdsmi_get_violation_status stays inside for STUB_VIOLATION_MS
+// (the real one sleeps 100 ms between two reads of its own), and a shut-down that arrives meanwhile ends the process.
+static std::atomic<int> g_inside{0};
+amdsmi_status_t amdsmi_shut_down(void) {
+  if (g_inside.load() != 0) {
+    fprintf(stderr, "amdsmi stub: amdsmi_shut_down while %d call(s) are inside the library\n", g_inside.load());
+    abort();
+  }
+  return AMDSMI_STATUS_SUCCESS;
+}
+amdsmi_status_t amdsmi_get_violation_status(amdsmi_processor_handle, amdsmi_violation_status_t* v) {
+  if (!v) return AMDSMI_STATUS_INVAL;
+  const int ms = env_int("STUB_VIOLATION_MS", -1);
+  if (ms < 0) return AMDSMI_STATUS_NOT_SUPPORTED;
+  g_inside++;
+  usleep((useconds_t)ms * 1000);
+  memset(v, 0xff, sizeof *v);
+  g_inside--;
+  return AMDSMI_STATUS_SUCCESS;
+}
 
 amdsmi_status_t amdsmi_get_socket_handles(uint32_t* n, amdsmi_socket_handle* h) {
   if (!n) return AMDSMI_STATUS_INVAL;

@@ -224,3 +224,27 @@ def test_partitions_are_enumerated_in_order_and_labelled(stub, tmp_path, tables)
     assert [d[1][-8:-4] for d in out["devices"]] == ["0000", "0001", "0002", "0003"] * 2
     assert [l["gpu"] for l in out["labels"]] == [str(i) for i in range(8)]
     assert [l["partition"] for l in out["labels"]] == ["0", "1", "2", "3"] * 2
+
+
+def test_shutdown_waits_for_the_calls_the_backend_has_inside_the_library(stub, tmp_path, tables):
+    """The first read of the throttle state starts a one-time cross-check on a thread of its own, because the library's
+    violation report sleeps 100 ms inside.  A short-lived caller shuts down well within that: the backend must wait for
+    its thread before it closes the library (on an MI355X host a caller that did not was left with a damaged heap one
+    time in four while another process kept the library busy).  The stand-in library stays inside for 300 ms and ends
+    the process if it is shut down meanwhile."""
+    idle = tables[0]
+    sysfs = tmp_path / "sys"
+    dev = sysfs / "bus" / "pci" / "devices" / "0000:10:00.0"
+    dev.mkdir(parents=True)
+    (dev / "gpu_metrics").write_bytes(idle)
+    (dev / "numa_node").write_text("0\n")
+    e = dict(os.environ, PYTHONPATH=ROOT, GPUMON_AMDSMI_LIB=str(stub), GPUMON_SYSFS_ROOT=str(sysfs), STUB_SYSFS=str(sysfs), STUB_GPUS="1",
+             GPUMON_PROC_ROOT=str(tmp_path / "noproc"), STUB_VIOLATION_MS="300")
+    e.pop("GPUMON_BACKEND", None)
+    code = ("import time; from k8s_gpu_monitor_amd import smi; t0 = time.time(); smi.init(backend='amdsmi'); s = smi.device_status(0); "
+            "t1 = time.time(); smi.shutdown(); print(s['power_w'], round(t1 - t0, 3), round(time.time() - t1, 3))")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=e)
+    assert r.returncode == 0, (r.returncode, r.stderr[-600:])
+    power, read_s, shutdown_s = r.stdout.split()
+    assert float(power) > 0 and float(read_s) < 0.25, r.stdout    # the read did not wait for the check ...
+    assert 0.05 < float(shutdown_s) < 2.0, r.stdout               # ... the shutdown did

@@ -312,22 +312,43 @@ def test_metrics_table_is_read_directly_and_agrees_with_the_library(hw, tmp_path
     assert v[F["MEM_CLOCK"]] == raw["current_uclk"] and abs(v[F["GPU_TEMP"]] - raw["temperature_hotspot"]) <= 5
     assert raw["num_partition"] == 1 and raw["pcie_link_width"] == 16
     # the same reading through the library, in a process of its own
-    # (faulthandler: should the device library fault in the child, its stderr says in which of the three calls.  That has
-    # happened once in a dozen runs of this test, with nothing on stderr; a child that dies of a signal is run once more,
-    # and the first death is reported as a warning with what it left.)
     code = ("import faulthandler, json, sys; faulthandler.enable(); from k8s_gpu_monitor_amd import smi; smi.init(backend='amdsmi'); "
-            f"print(json.dumps(smi.device_status({gpu})), flush=True); smi.shutdown(); print('closed', file=sys.stderr)")
+            f"print(json.dumps(smi.device_status({gpu})), flush=True); smi.shutdown()")
     env = dict(os.environ, GPUMON_METRICS_TABLE="library", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
-    if r.returncode < 0:
-        import warnings
-        warnings.warn(f"the library-mode child died of signal {-r.returncode}; stdout {r.stdout[-200:]!r}; stderr {r.stderr[-800:]!r}")
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, (r.returncode, r.stdout[-200:], r.stderr[-800:])
     lib_status = json.loads(r.stdout.strip().splitlines()[-1])
     here = E.device_status(gpu)
     assert lib_status["mem_clock_mhz"] == here["mem_clock_mhz"] and abs(lib_status["temperature_c"] - here["temperature_c"]) <= 5
     assert 0 <= here["energy_mj"] - lib_status["energy_mj"] < 600_000  # same accumulator, read a moment later: under 600 J apart
+
+
+def test_short_lived_callers_leave_cleanly_beside_a_busy_engine(hw):
+    """A process that opens the device layer, reads one status and closes it again, while this process's engine samples
+    the same GPU at 100 ms: none of forty may die.  (One in four did, of a damaged heap at interpreter exit: the backend's
+    one-time cross-check of the violation report ran on a detached thread that was still asleep inside the device
+    library when the library was shut down.  The thread is joined now; tests/test_amdsmi_backend_stub.py holds the
+    same on the CPU.)"""
+    import subprocess
+    import sys
+    gpu = _engine_index_of_hip0()
+    g = E.group_create("busy", [gpu])
+    ids = [F["POWER_USAGE"], F["GPU_TEMP"], F["ECC_CE_VOLATILE"], F["VRAM_USED"], F["THROTTLE_STATUS"]]
+    fg = E.field_group_create("busy", ids)
+    code = f"from k8s_gpu_monitor_amd import smi; smi.init(backend='amdsmi'); smi.device_status({gpu}); smi.shutdown()"
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        E.watch_fields(g, fg, update_freq_us=100_000)
+        died = []
+        for i in range(40):
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
+            if r.returncode != 0:
+                died.append((i, r.returncode, r.stderr[-300:]))
+        assert not died, died
+    finally:
+        E.unwatch_fields(g, fg)
+        E.group_destroy(g)
+        E.field_group_destroy(fg)
 
 
 def test_micro_benchmarks(hw):
