@@ -68,7 +68,7 @@ const char* kFlagsWithValue[] = {"-g", "--bytes", "--iters", "--kernel", "--min-
                                  "--max-bytes", "-r", "--chunk", "--min-tflops", "--factor", "--publish", "--modes", "--floor-gbps",
                                  "--warn-ratio", "--fail-ratio", "--workgroups", "--submit", "--min-busbw", "--expect", "--expect-scale",
                                  "--check-every", "--direction", "--link-gbps", "--outlier-warn", "--outlier-fail", "--arch", "--name", "--check",
-                                 "--pcie-gen", "--pcie-width"};
+                                 "--pcie-gen", "--pcie-width", "--backend", "--expect-gpus"};
 
 bool parse(const std::vector<std::string>& in, Args* a) {
   for (size_t i = 0; i < in.size(); i++) {
@@ -1397,6 +1397,187 @@ void compare_gpus(const Args& a, Report& r) {
   r.member("node", nj + "}");
 }
 
+// Deployment checks: nothing is loaded, the node is only looked at.  What NVIDIA's diagnostic calls its software level
+// (libraries, permissions, device nodes) plus what goes wrong on an 8-GPU AMD node before any kernel runs: a GPU that
+// the compute runtime does not see, a device node the user may not open, a host link that trained below what the card
+// supports, a lowered power cap, pages waiting for retirement, one GPU on another VBIOS or in another partition mode
+// than its seven neighbours.  One verdict per GPU and concern; the report is a node report.
+int cmd_preflight(const Args& a, Report& r) {
+  r.gpu = -1;
+  const std::string backend = a.str("--backend");
+  gm_init_params_t p;
+  memset(&p, 0, sizeof p);
+  p.version = GM_INIT_PARAMS_VERSION;
+  p.mode = GM_MODE_EMBEDDED;
+  p.backend = backend.empty() ? nullptr : backend.c_str();
+  gm_status_t st = gm_init(&p);
+  if (st != GM_ST_OK) {
+    r.text("device library: %s\n", gm_strerror(st));
+    r.verdict_fail("preflight_runtime", GM_HEALTH_WATCH_DRIVER, 0, "the device library cannot be used: %s", gm_strerror(st));
+    return 0;
+  }
+  uint32_t n = 0;
+  gm_device_count(&n);
+  std::vector<gm_device_attributes_t> at(n);
+  for (uint32_t i = 0; i < n; i++) {
+    memset(&at[i], 0, sizeof at[i]);
+    at[i].version = GM_DEVICE_ATTRIBUTES_VERSION;
+    if (gm_device_attributes(i, &at[i]) != GM_ST_OK) at[i].supported = 0;
+  }
+  auto verdict = [&](uint32_t g, const char* test, uint32_t system, int health, double value, const std::string& msg) {
+    r.verdict_for_gpu((int)g, test, system, health, value, msg);
+    for (auto& v : r.verdicts)
+      if (v.test == test && v.gpu == (int)g) v.pci_bdf = at[g].pci_bdf;
+  };
+  auto first_line = [](const std::string& path) {
+    std::string s;
+    if (FILE* f = fopen(path.c_str(), "r")) {
+      char buf[160];
+      if (fgets(buf, sizeof buf, f)) s = buf;
+      fclose(f);
+    }
+    while (!s.empty() && (s.back() == '\n' || s.back() == ' ')) s.pop_back();
+    return s;
+  };
+  auto gen_of = [](double gts) { return gts >= 63 ? 6 : gts >= 31 ? 5 : gts >= 15 ? 4 : gts >= 7.5 ? 3 : gts >= 4.5 ? 2 : gts >= 2 ? 1 : 0; };
+
+  // ---- the node: driver, device nodes, the two views of the GPU count
+  const std::string drv = first_line("/sys/module/amdgpu/version");
+  const bool rocm_host = access("/dev/kfd", F_OK) == 0;
+  r.text("device library: %u GPU(s)%s%.48s\n", n, n && at[0].driver_version[0] ? ", driver " : "", n ? at[0].driver_version : "");
+  if (!drv.empty()) r.text("amdgpu module: %s\n", drv.c_str());
+  std::string node = "{\"gpus\":" + std::to_string(n) + ",\"amdgpu_module\":" + jstr(drv);
+  const int want = (int)a.num("--expect-gpus", 0);
+  int runtime_health = GM_HEALTH_PASS;
+  std::string runtime_msg = "device library and compute runtime agree";
+  if (want > 0 && (int)n != want) {
+    runtime_health = GM_HEALTH_FAIL;
+    runtime_msg = strprintf_local("%u GPU(s) enumerated, %d expected", n, want);
+  }
+  if (rocm_host && access("/dev/kfd", R_OK | W_OK) != 0) {
+    runtime_health = GM_HEALTH_FAIL;
+    runtime_msg = strprintf_local("/dev/kfd is not readable and writable by uid %d (render / video group)", (int)getuid());
+  }
+  if (!a.has("--no-runtime")) {
+    const int hip = gmd_device_count();
+    node += ",\"runtime_gpus\":" + std::to_string(hip);
+    const char* hidden = getenv("HIP_VISIBLE_DEVICES") ? "HIP_VISIBLE_DEVICES" : getenv("ROCR_VISIBLE_DEVICES") ? "ROCR_VISIBLE_DEVICES" : nullptr;
+    r.text("compute runtime: %d GPU(s)%s%s\n", std::max(hip, 0), hidden ? ", limited by " : "", hidden ? hidden : "");
+    if (hip <= 0) {
+      runtime_health = GM_HEALTH_FAIL;
+      runtime_msg = strprintf_local("the compute runtime sees no GPU (%s)", gmd_last_error());
+    } else if ((uint32_t)hip != n && runtime_health < GM_HEALTH_FAIL) {
+      // fewer with a visibility variable set is the operator's doing; anything else is a GPU that one side has lost
+      runtime_health = hidden && (uint32_t)hip < n ? GM_HEALTH_WARN : GM_HEALTH_FAIL;
+      runtime_msg = strprintf_local("the device library has %u GPU(s), the compute runtime %d%s", n, hip,
+                                    hidden ? " (a visibility variable is set)" : " (a device-cgroup rule, or a GPU that fell off the bus)");
+    }
+  }
+  r.verdict("preflight_runtime", GM_HEALTH_WATCH_DRIVER, runtime_health, (double)n, runtime_msg);
+  r.member("node", node + "}");
+
+  // ---- memory state of every GPU: one forced sample of the counters that matter before a job starts
+  const uint16_t ids[] = {GM_FI_BAD_PAGES_PENDING, GM_FI_BAD_PAGES_UE, GM_FI_ECC_UE_VOLATILE, GM_FI_ECC_CE_VOLATILE};
+  std::vector<std::vector<gm_value_t>> vals(n, std::vector<gm_value_t>(4));
+  if (n) {
+    gm_group_t grp = 0;
+    gm_field_group_t fg = 0;
+    if (gm_group_create("preflight", &grp) == GM_ST_OK && gm_field_group_create(ids, 4, "preflight", &fg) == GM_ST_OK) {
+      for (uint32_t i = 0; i < n; i++) gm_group_add_device(grp, i);
+      gm_watch_fields(grp, fg, 1000000, 60.0, 2);
+      gm_update_all_fields(1);
+      for (uint32_t i = 0; i < n; i++) gm_latest_values(i, ids, 4, vals[i].data());
+      gm_unwatch_fields(grp, fg);
+      gm_field_group_destroy(fg);
+      gm_group_destroy(grp);
+    }
+  }
+  auto num = [](const gm_value_t& v) { return v.status != GM_VS_OK ? -1.0 : v.type == GM_FT_DOUBLE ? v.v.dbl : (double)v.v.i64; };
+
+  // ---- what the GPUs of a node should have in common: the value most of them have is the node's
+  struct Common { const char* what; std::function<std::string(const gm_device_attributes_t&)> of; };
+  const Common common[] = {{"VBIOS", [](const gm_device_attributes_t& x) { return std::string(x.vbios); }},
+                           {"firmware", [](const gm_device_attributes_t& x) { return std::string(x.firmware); }},
+                           {"product", [](const gm_device_attributes_t& x) { return std::string(x.name); }},
+                           {"compute partition", [](const gm_device_attributes_t& x) { return std::string(x.compute_partition); }},
+                           {"memory partition", [](const gm_device_attributes_t& x) { return std::string(x.memory_partition); }},
+                           {"HBM size", [](const gm_device_attributes_t& x) { return std::to_string(x.vram_total_mib) + " MiB"; }}};
+  std::vector<std::string> odd(n);
+  for (const Common& c : common) {
+    std::map<std::string, int> count;
+    for (uint32_t i = 0; i < n; i++) count[c.of(at[i])]++;
+    if (count.size() < 2) continue;
+    std::string most;
+    for (auto& kv : count)
+      if (most.empty() || kv.second > count[most]) most = kv.first;
+    for (uint32_t i = 0; i < n; i++)
+      if (c.of(at[i]) != most) odd[i] += (odd[i].empty() ? "" : "; ") + std::string(c.what) + " " + c.of(at[i]) + ", most GPUs of the node have " + most;
+  }
+
+  r.text("%-3s %-13s %-22s %-14s %-9s %-5s %-14s %-11s %s\n", "gpu", "pci", "product", "vbios", "partition", "numa", "host link", "power cap", "pages");
+  std::string arr = "[";
+  for (uint32_t i = 0; i < n; i++) {
+    const gm_device_attributes_t& x = at[i];
+    // device node
+    int access_health = GM_HEALTH_PASS;
+    std::string access_msg = "device node can be opened";
+    if (!x.supported) access_health = GM_HEALTH_WARN, access_msg = "not a device this stack samples in full (not a CDNA-class GPU)";
+    if (x.device_path[0] && (rocm_host || access(x.device_path, F_OK) == 0) && access(x.device_path, R_OK | W_OK) != 0) {
+      access_health = GM_HEALTH_FAIL;
+      access_msg = strprintf_local("%s is not readable and writable by uid %d (render / video group)", x.device_path, (int)getuid());
+    }
+    verdict(i, "preflight_access", GM_HEALTH_WATCH_DRIVER, access_health, 0, access_msg);
+    // host link: what it trained to against what the card supports
+    const std::string dir = std::string("/sys/bus/pci/devices/") + x.pci_bdf + "/";
+    const int cur_gen = gen_of(atof(first_line(dir + "current_link_speed").c_str())), cur_w = atoi(first_line(dir + "current_link_width").c_str());
+    int max_gen = gen_of(atof(first_line(dir + "max_link_speed").c_str())), max_w = atoi(first_line(dir + "max_link_width").c_str());
+    if (max_gen <= 0) max_gen = (int)x.pcie_max_gen;
+    if (max_w <= 0) max_w = (int)x.pcie_max_width;
+    std::string link = cur_gen > 0 && cur_w > 0 ? strprintf_local("gen%d x%d", cur_gen, cur_w) : "-";
+    if (cur_gen > 0 && cur_w > 0) {
+      const bool low = (max_gen > 0 && cur_gen < max_gen) || (max_w > 0 && cur_w < max_w);
+      if (low) link += strprintf_local(" of gen%d x%d", max_gen, max_w);
+      verdict(i, "preflight_pcie", GM_HEALTH_WATCH_PCIE, low ? GM_HEALTH_WARN : GM_HEALTH_PASS, cur_gen * 100 + cur_w,
+              low ? strprintf_local("host link trained to generation %d x%d, the device supports generation %d x%d (slot, riser or reseat)", cur_gen, cur_w, max_gen, max_w)
+                  : "host link at the generation and width the device supports");
+    }
+    // power cap
+    std::string cap = std::isfinite(x.power_cap_w) ? strprintf_local("%.0f W", x.power_cap_w) : "-";
+    if (std::isfinite(x.power_cap_w) && std::isfinite(x.power_cap_default_w) && x.power_cap_default_w > 0) {
+      const bool low = x.power_cap_w < x.power_cap_default_w - 0.5;
+      if (low) cap += strprintf_local(" of %.0f", x.power_cap_default_w);
+      verdict(i, "preflight_power", GM_HEALTH_WATCH_POWER, low ? GM_HEALTH_WARN : GM_HEALTH_PASS, x.power_cap_w,
+              low ? strprintf_local("power cap %.0f W is under the default %.0f W", x.power_cap_w, x.power_cap_default_w) : "power cap at its default");
+    }
+    // memory
+    const double pending = num(vals[i][0]), retired_ue = num(vals[i][1]), ue = num(vals[i][2]), ce = num(vals[i][3]);
+    std::string pages = pending < 0 && retired_ue < 0 ? "-" : strprintf_local("%.0f pending, %.0f retired", std::max(pending, 0.0), std::max(retired_ue, 0.0));
+    if (pending >= 0 || ue >= 0) {
+      int h = GM_HEALTH_PASS;
+      std::string msg = "no uncorrectable errors since the driver was loaded, no pages waiting for retirement";
+      if (pending > 0) h = GM_HEALTH_WARN, msg = strprintf_local("%.0f page(s) wait for retirement at the next driver load", pending);
+      if (ue > 0) h = GM_HEALTH_FAIL, msg = strprintf_local("%.0f uncorrectable ECC error(s) since the driver was loaded", ue);
+      verdict(i, "preflight_memory", GM_HEALTH_WATCH_MEM, h, std::max(ue, 0.0) + std::max(pending, 0.0), msg);
+    }
+    // the odd one out
+    if (n > 1) verdict(i, "preflight_uniform", GM_HEALTH_WATCH_FIRMWARE, odd[i].empty() ? GM_HEALTH_PASS : GM_HEALTH_WARN, 0,
+                       odd[i].empty() ? "VBIOS, firmware, product, partition modes and HBM size as on the other GPUs" : odd[i]);
+    const std::string part = std::string(x.compute_partition[0] ? x.compute_partition : "-") + "/" + (x.memory_partition[0] ? x.memory_partition : "-");
+    r.text("%-3u %-13s %-22.22s %-14.14s %-9s %-5d %-14s %-11s %s\n", i, x.pci_bdf, x.name, x.vbios[0] ? x.vbios : "-", part.c_str(), x.numa_node, link.c_str(),
+           cap.c_str(), pages.c_str());
+    arr += std::string(i ? "," : "") + "{\"gpu\":" + std::to_string(i) + ",\"pci_bdf\":" + jstr(x.pci_bdf) + ",\"name\":" + jstr(x.name) + ",\"vbios\":" + jstr(x.vbios) +
+           ",\"firmware\":" + jstr(x.firmware) + ",\"compute_partition\":" + jstr(x.compute_partition) + ",\"memory_partition\":" + jstr(x.memory_partition) +
+           ",\"numa_node\":" + std::to_string(x.numa_node) + ",\"link_gen\":" + std::to_string(cur_gen) + ",\"link_width\":" + std::to_string(cur_w) +
+           ",\"link_max_gen\":" + std::to_string(max_gen) + ",\"link_max_width\":" + std::to_string(max_w) + ",\"power_cap_w\":" + jnum(x.power_cap_w) +
+           ",\"power_cap_default_w\":" + jnum(x.power_cap_default_w) + ",\"pages_pending\":" + jnum(pending < 0 ? NAN : pending) +
+           ",\"ecc_ue\":" + jnum(ue < 0 ? NAN : ue) + ",\"ecc_ce\":" + jnum(ce < 0 ? NAN : ce) + "}";
+  }
+  r.member("devices", arr + "]");
+  gm_shutdown();
+  return 0;
+}
+
+
 // gpumon-diag expect [--arch gfx950] [--name "AMD Instinct MI355X"] [--expect ..] [--expect-scale F] [--check key=value,..]
 // What a GPU is held against, without needing one: the table entry for an architecture / product name (default:
 // GPU 0 when one is visible, else gfx950), and with --check the grade of given measurements.
@@ -1504,8 +1685,9 @@ int cmd_run(const Args& a, Report& r, const std::vector<int>& gpus, MfmaWatch* m
 
 void usage() {
   fprintf(stderr,
-          "usage: gpumon-diag <info|expect|hbm|memtest|pcie|mfma|gemm|rccl|links|run> [options] [--json] [--publish FILE]\n"
+          "usage: gpumon-diag <info|preflight|expect|hbm|memtest|pcie|mfma|gemm|rccl|links|run> [options] [--json] [--publish FILE]\n"
           "  --publish FILE leaves the JSON report where `gpumon-exporter --diag-results` picks it up\n"
+          "  preflight [--expect-gpus N] [--no-runtime] [--backend amdsmi|fake]   deployment checks; loads nothing\n"
           "  hbm     [-g GPU | --gpus LIST|all] [--bytes N] [--iters N] [--kernel copy|scale|add|triad|read|write|all] [--min-tbps X]\n"
           "  memtest [-g GPU | --gpus LIST|all] [--bytes N | --fraction F] [--chunk N] [--patterns LIST] [--passes N] [--march]\n"
           "  pcie    [-g GPU | --gpus LIST|all] [--bytes N] [--iters N] [--pcie-gen G --pcie-width W]   host link: copy engines and kernels over pinned memory\n"
@@ -1614,6 +1796,7 @@ int main(int argc, char** argv) {
     }
   }
   if (cmd == "info") rc = cmd_info(a, r);
+  else if (cmd == "preflight") rc = cmd_preflight(a, r);
   else if (cmd == "expect") rc = cmd_expect(a, r);
   else if (cmd == "hbm") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_hbm(x, y, g); });
   else if (cmd == "memtest") rc = run_on(a, r, gpus, [](const Args& x, Report& y, int g) { return cmd_memtest(x, y, g); });

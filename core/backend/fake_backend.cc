@@ -60,6 +60,9 @@ class FakeBackend : public Backend {
       else if (k == "sample_cost_us") sample_cost_us_ = atoi(v.c_str());
       else if (k == "steady") steady_ = atoi(v.c_str()) != 0;  // telemetry independent of the sample count
       else if (k == "partition_mode") partition_mode_ = v;       // e.g. CPX: every entry is one of 8 partitions of a GPU
+      // control commands run at the end of init, '+' for the blanks and ';' between commands (a spec has no blanks and
+      // its commas separate keys): at_start=bad_pages+gpu=2+pending=3;static+gpu=5+vbios=113-OLD
+      else if (k == "at_start") at_start_ = v;
     }
     if (ngpus_ > GM_MAX_GPUS) ngpus_ = GM_MAX_GPUS;
   }
@@ -68,6 +71,16 @@ class FakeBackend : public Backend {
 
   gm_status_t init() override {
     if (fail_init_) return GM_ST_INIT_ERROR;
+    gm_status_t st = init_devices();
+    if (st != GM_ST_OK) return st;
+    std::string cmds = at_start_;
+    std::replace(cmds.begin(), cmds.end(), '+', ' ');
+    for (auto& c : split(cmds, ';'))
+      if (!trim(c).empty() && (st = control(trim(c))) != GM_ST_OK) return st;
+    return GM_ST_OK;
+  }
+
+  gm_status_t init_devices() {
     std::lock_guard<std::mutex> l(mu_);
     gpus_.assign(ngpus_, FakeGpu());
     for (uint32_t i = 0; i < ngpus_; i++) {
@@ -479,6 +492,12 @@ class FakeBackend : public Backend {
         g.ecc_ce[b] += geti("ce", 0);
         g.ecc_ue[b] += geti("ue", 0);
         g.ecc_deferred += geti("deferred", 0);
+      } else if (verb == "static") {  // what a device reports about itself: one GPU unlike its neighbours
+        if (kv.count("vbios")) g.st.vbios = kv["vbios"];
+        if (kv.count("firmware")) g.st.firmware = kv["firmware"];
+        if (kv.count("power_cap")) g.st.power_cap_w = getd("power_cap", g.st.power_cap_w);
+        if (kv.count("compute_partition")) g.st.compute_partition = kv["compute_partition"];
+        if (kv.count("supported")) g.st.supported = geti("supported", 1) != 0;
       } else if (verb == "bad_pages") {
         g.bad_ce += geti("ce", 0); g.bad_ue += geti("ue", 0); g.bad_pending += geti("pending", 0);
       } else if (verb == "pcie_replay") {
@@ -525,6 +544,7 @@ class FakeBackend : public Backend {
   std::unique_ptr<ProfChildSampler> prof_child_;
   bool fail_init_ = false, events_supported_ = true, topology_unsupported_ = false, steady_ = false;
   std::string partition_mode_;
+  std::string at_start_;
   double default_load_ = 0;
   int unsupported_gpu_ = -1;
   int sample_cost_us_ = 0;

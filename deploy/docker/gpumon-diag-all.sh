@@ -9,6 +9,7 @@
 #   GPUMON_DIAG_DIR         report directory (default /var/lib/gpumon/diag)
 #   GPUMON_DIAG_SUBMIT      address of a host engine that also gets the verdicts (e.g. 127.0.0.1:5555); empty = none
 #   GPUMON_DIAG_SEQUENTIAL  1 = one GPU after the other (one report per GPU, no comparison between GPUs)
+#   GPUMON_DIAG_EXPECT_GPUS number of GPUs the node should have (the deployment checks fail on another count)
 set -u
 LEVEL=${GPUMON_DIAG_LEVEL:-2}
 DIR=${GPUMON_DIAG_DIR:-/var/lib/gpumon/diag}
@@ -31,6 +32,9 @@ note() {  # keep the worst status: 2 (could not run) over 1 (failed) over 0
   [ "$1" -gt "$worst" ] && worst=$1
   return 0
 }
+echo "=== deployment checks"
+"$DIAG" preflight ${GPUMON_DIAG_EXPECT_GPUS:+--expect-gpus "$GPUMON_DIAG_EXPECT_GPUS"} --publish "$DIR/preflight.json" "${extra[@]}"
+note $?
 if [ "${GPUMON_DIAG_SEQUENTIAL:-0}" = 1 ]; then
   rm -f "$DIR/node.json"  # the report of an earlier concurrent run would contradict the ones written now
   for ((g = 0; g < n; g++)); do

@@ -209,26 +209,30 @@ exit 0
         return r.returncode, calls, sorted(p.name for p in out.iterdir()) if out.exists() else []
 
     rc, calls, files = run(1)
-    assert rc == 0 and calls == ["info", f"run -r 2 --gpus all --no-fabric --publish {tmp_path}/out10/node.json"] and files == ["node.json"]
+    assert rc == 0 and files == ["node.json", "preflight.json"]
+    assert calls == ["info", f"preflight --publish {tmp_path}/out10/preflight.json", f"run -r 2 --gpus all --no-fabric --publish {tmp_path}/out10/node.json"]
     # all GPUs at once; the fabric tests once
     rc, calls, files = run(8, GPUMON_DIAG_LEVEL="3", GPUMON_DIAG_SUBMIT="127.0.0.1:5555", STUB_FAIL_NODE="1")
-    assert rc == 1 and len(calls) == 4 and files == ["links.json", "node.json", "rccl.json"]
-    assert calls[1].startswith("run -r 3 --gpus all --no-fabric --publish") and calls[1].endswith("--submit 127.0.0.1:5555")
-    assert calls[2].startswith("links --publish") and calls[3].startswith("rccl --scaling --publish")
+    assert rc == 1 and len(calls) == 5 and files == ["links.json", "node.json", "preflight.json", "rccl.json"]
+    assert calls[1].startswith("preflight --publish") and calls[1].endswith("--submit 127.0.0.1:5555")  # the deployment checks come first
+    assert calls[2].startswith("run -r 3 --gpus all --no-fabric --publish") and calls[2].endswith("--submit 127.0.0.1:5555")
+    assert calls[3].startswith("links --publish") and calls[4].startswith("rccl --scaling --publish")
     rc, calls, files = run(2, X="1")
-    assert rc == 0 and calls[3].startswith("rccl --max-bytes 256M --factor 16 --publish")
+    assert rc == 0 and calls[4].startswith("rccl --max-bytes 256M --factor 16 --publish")
+    rc, calls, files = run(8, GPUMON_DIAG_EXPECT_GPUS="8", X="1", Y="2", Z="3")
+    assert calls[1].startswith("preflight --expect-gpus 8 --publish")
     # one GPU after the other, when asked for
     rc, calls, files = run(3, GPUMON_DIAG_LEVEL="1", GPUMON_DIAG_SEQUENTIAL="1", STUB_FAIL_GPU="1")
-    assert rc == 1 and len(calls) == 1 + 3 + 2 and files == ["gpu0.json", "gpu1.json", "gpu2.json", "links.json", "rccl.json"]
-    assert calls[2].startswith("run -r 1 -g 1 --no-fabric ")
+    assert rc == 1 and len(calls) == 2 + 3 + 2 and files == ["gpu0.json", "gpu1.json", "gpu2.json", "links.json", "preflight.json", "rccl.json"]
+    assert calls[3].startswith("run -r 1 -g 1 --no-fabric ")
     assert run(0)[0] == 2
     rc, calls, files = run(4, GPUMON_DIAG_SEQUENTIAL="1", STUB_CRASH_GPU="1", X="1", Y="2")  # GPU 1's run dies: GPUs 2 and 3, links and RCCL are not started
-    assert rc == 2 and [c.split()[0:5] for c in calls[1:]] == [["run", "-r", "2", "-g", "0"], ["run", "-r", "2", "-g", "1"]]
+    assert rc == 2 and [c.split()[0:5] for c in calls[2:]] == [["run", "-r", "2", "-g", "0"], ["run", "-r", "2", "-g", "1"]]
     rc, calls, files = run(4, STUB_CRASH_NODE="1", X="1")      # the concurrent run dies: no fabric test is started
-    assert rc == 2 and len(calls) == 2
+    assert rc == 2 and len(calls) == 3
     # every flag the script passes is one the real binary parses
     src = open(os.path.join(ROOT, "cmd", "gpumon-diag.cc")).read()
-    for flag in ("-r", "-g", "--gpus", "--publish", "--submit", "--max-bytes", "--factor"):
+    for flag in ("-r", "-g", "--gpus", "--publish", "--submit", "--max-bytes", "--factor", "--expect-gpus"):
         assert f'"{flag}"' in src, flag
     for flag in ("--no-fabric", "--scaling"):
         assert f'"{flag}"' in src, flag

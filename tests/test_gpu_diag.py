@@ -672,6 +672,22 @@ def _run_diag(*args, timeout=110, env=None):
     return r.returncode, json.loads(r.stdout)
 
 
+def test_cli_preflight_on_this_host():
+    """The deployment checks on a real node: the device library and the compute runtime see the same GPU, its device node
+    opens, the host link sits at what the card supports, no page waits for retirement (tests/test_preflight.py seeds the
+    faults on the fake backend)."""
+    rc, doc = _run_diag("preflight", "--expect-gpus", "1")
+    assert rc == 0 and doc["result"] in ("pass", "warn") and doc["scope"] == "node", doc["verdicts"]
+    assert doc["node"]["gpus"] == doc["node"]["runtime_gpus"] == 1
+    by = {v["test"]: v for v in doc["verdicts"]}
+    assert {"preflight_runtime", "preflight_access", "preflight_pcie", "preflight_memory"} <= set(by), sorted(by)
+    assert by["preflight_runtime"]["health"] == 0 and by["preflight_access"]["health"] == 0 and by["preflight_memory"]["health"] == 0, by
+    d = doc["devices"][0]
+    assert d["pci_bdf"] == by["preflight_access"]["pci_bdf"] and d["link_gen"] >= 3 and d["link_width"] in (8, 16) and d["ecc_ue"] == 0
+    rc, doc = _run_diag("preflight", "--expect-gpus", "8")
+    assert rc == 1 and "1 GPU(s) enumerated, 8 expected" in {v["test"]: v for v in doc["verdicts"]}["preflight_runtime"]["message"]
+
+
 def test_cli_soak_at_an_operators_shape_says_how_it_ran():
     """`gpumon-diag gemm --m --n --k`: a shape off the table is graded on correctness alone; the report says into how many
     ranges of K the launcher split it and that every launch was held against the first."""
