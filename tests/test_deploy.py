@@ -243,6 +243,8 @@ exit 0
     pod = cron["spec"]["jobTemplate"]["spec"]["template"]["spec"]
     assert cron["kind"] == "CronJob" and pod["restartPolicy"] == "Never" and pod["nodeSelector"] == {"hardware-type": "AMDGPU"}
     assert pod["containers"][0]["resources"]["limits"] == {"amd.com/gpu": 8}
+    env = {e["name"]: e["value"] for e in pod["containers"][0]["env"]}
+    assert env["GPUMON_DIAG_EXPECT_GPUS"] == "8"        # a GPU that fell off the bus fails the deployment checks
     assert pod["volumes"][0]["hostPath"]["path"] == "/var/lib/gpumon/diag"
 
 
