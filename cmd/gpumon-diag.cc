@@ -1442,7 +1442,9 @@ int cmd_preflight(const Args& a, Report& r) {
   auto gen_of = [](double gts) { return gts >= 63 ? 6 : gts >= 31 ? 5 : gts >= 15 ? 4 : gts >= 7.5 ? 3 : gts >= 4.5 ? 2 : gts >= 2 ? 1 : 0; };
 
   // ---- the node: driver, device nodes, the two views of the GPU count
-  const std::string drv = first_line("/sys/module/amdgpu/version");
+  // the same override the device layer takes: tests lay out a sysfs tree of their own
+  const std::string sys = getenv("GPUMON_SYSFS_ROOT") && *getenv("GPUMON_SYSFS_ROOT") ? getenv("GPUMON_SYSFS_ROOT") : "/sys";
+  const std::string drv = first_line(sys + "/module/amdgpu/version");
   const bool rocm_host = access("/dev/kfd", F_OK) == 0;
   r.text("device library: %u GPU(s)%s%.48s\n", n, n && at[0].driver_version[0] ? ", driver " : "", n ? at[0].driver_version : "");
   if (!drv.empty()) r.text("amdgpu module: %s\n", drv.c_str());
@@ -1528,7 +1530,7 @@ int cmd_preflight(const Args& a, Report& r) {
     }
     verdict(i, "preflight_access", GM_HEALTH_WATCH_DRIVER, access_health, 0, access_msg);
     // host link: what it trained to against what the card supports
-    const std::string dir = std::string("/sys/bus/pci/devices/") + x.pci_bdf + "/";
+    const std::string dir = sys + "/bus/pci/devices/" + x.pci_bdf + "/";
     const int cur_gen = gen_of(atof(first_line(dir + "current_link_speed").c_str())), cur_w = atoi(first_line(dir + "current_link_width").c_str());
     int max_gen = gen_of(atof(first_line(dir + "max_link_speed").c_str())), max_w = atoi(first_line(dir + "max_link_width").c_str());
     if (max_gen <= 0) max_gen = (int)x.pcie_max_gen;

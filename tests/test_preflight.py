@@ -56,6 +56,29 @@ def test_seeded_faults_are_named_with_gpu_concern_and_subsystem():
     assert "GPU 6" in err and "FAIL" in err
 
 
+def test_a_host_link_that_trained_low_is_found_from_sysfs(tmp_path):
+    """The link state comes from the PCI device's sysfs files (what the kernel negotiated against what the card can do)."""
+    rc, doc, _ = preflight("gpus=4")
+    bdfs = [d["pci_bdf"] for d in doc["devices"]]
+    assert not by_gpu(doc, "preflight_pcie")  # no sysfs entry for a scripted GPU: no verdict, not a guess
+    for g, bdf in enumerate(bdfs):
+        d = tmp_path / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "current_link_speed").write_text("16.0 GT/s PCIe\n" if g == 3 else "32.0 GT/s PCIe\n")
+        (d / "current_link_width").write_text("8\n" if g == 3 else "16\n")
+        (d / "max_link_speed").write_text("32.0 GT/s PCIe\n")
+        (d / "max_link_width").write_text("16\n")
+    (tmp_path / "module" / "amdgpu").mkdir(parents=True)
+    (tmp_path / "module" / "amdgpu" / "version").write_text("6.16.6\n")
+    rc, doc, err = preflight("gpus=4", env={"GPUMON_SYSFS_ROOT": str(tmp_path)})
+    link = by_gpu(doc, "preflight_pcie")
+    assert rc == 0 and doc["result"] == "warn" and doc["node"]["amdgpu_module"] == "6.16.6"
+    assert sorted(link) == [0, 1, 2, 3] and [g for g, v in link.items() if v["health"]] == [3]
+    assert link[3]["health"] == WARN and link[3]["system"] == PCIE and link[3]["value"] == 408
+    assert "generation 4 x8" in link[3]["message"] and "generation 5 x16" in link[3]["message"]
+    assert doc["devices"][3]["link_gen"] == 4 and doc["devices"][3]["link_width"] == 8 and doc["devices"][0]["link_gen"] == 5
+
+
 def test_the_gpu_count_is_held_against_what_the_node_should_have():
     rc, doc, _ = preflight("gpus=7", "--expect-gpus", "8")
     v = by_gpu(doc, "preflight_runtime")[None]
