@@ -1401,7 +1401,8 @@ void compare_gpus(const Args& a, Report& r) {
 // (libraries, permissions, device nodes) plus what goes wrong on an 8-GPU AMD node before any kernel runs: a GPU that
 // the compute runtime does not see, a device node the user may not open, a host link that trained below what the card
 // supports, a lowered power cap, pages waiting for retirement, one GPU on another VBIOS or in another partition mode
-// than its seven neighbours.  One verdict per GPU and concern; the report is a node report.
+// than its seven neighbours, an xGMI link that did not train.  One verdict per GPU and concern; the report is a node
+// report.
 int cmd_preflight(const Args& a, Report& r) {
   r.gpu = -1;
   const std::string backend = a.str("--backend");
@@ -1516,7 +1517,7 @@ int cmd_preflight(const Args& a, Report& r) {
       if (c.of(at[i]) != most) odd[i] += (odd[i].empty() ? "" : "; ") + std::string(c.what) + " " + c.of(at[i]) + ", most GPUs of the node have " + most;
   }
 
-  r.text("%-3s %-13s %-22s %-14s %-9s %-5s %-14s %-11s %s\n", "gpu", "pci", "product", "vbios", "partition", "numa", "host link", "power cap", "pages");
+  r.text("%-3s %-13s %-22s %-14s %-9s %-5s %-14s %-11s %s\n", "gpu", "pci", "product", "vbios", "partition", "numa", "host link", "power cap", "xgmi  pages");
   std::string arr = "[";
   for (uint32_t i = 0; i < n; i++) {
     const gm_device_attributes_t& x = at[i];
@@ -1561,17 +1562,41 @@ int cmd_preflight(const Args& a, Report& r) {
       if (ue > 0) h = GM_HEALTH_FAIL, msg = strprintf_local("%.0f uncorrectable ECC error(s) since the driver was loaded", ue);
       verdict(i, "preflight_memory", GM_HEALTH_WATCH_MEM, h, std::max(ue, 0.0) + std::max(pending, 0.0), msg);
     }
+    // fabric: every wired xGMI link is up (a link that did not train takes its traffic over the others, or over the host)
+    int links_up = -1, links_wired = 0;
+    if (n > 1) {
+      gm_xgmi_link_t lk[GM_MAX_XGMI_LINKS];
+      int nl = GM_MAX_XGMI_LINKS;
+      if (gm_xgmi_links(i, lk, &nl) == GM_ST_OK && nl > 0) {
+        links_up = 0;
+        std::string down;
+        for (int l = 0; l < nl; l++) {
+          if (lk[l].state < 0) continue;
+          links_wired++;
+          if (lk[l].state == 1) { links_up++; continue; }
+          down += (down.empty() ? "" : ", ") + std::to_string(lk[l].link);
+          if (lk[l].peer_gpu >= 0) down += " (to GPU " + std::to_string(lk[l].peer_gpu) + ")";
+          else if (lk[l].peer_bdf[0]) down += std::string(" (to ") + lk[l].peer_bdf + ")";
+        }
+        if (links_wired)
+          verdict(i, "preflight_fabric", GM_HEALTH_WATCH_XGMI, down.empty() ? GM_HEALTH_PASS : GM_HEALTH_FAIL, links_up,
+                  down.empty() ? strprintf_local("%d of %d xGMI links up", links_up, links_wired)
+                               : strprintf_local("xGMI link %s down: %d of %d links up", down.c_str(), links_up, links_wired));
+      }
+    }
     // the odd one out
     if (n > 1) verdict(i, "preflight_uniform", GM_HEALTH_WATCH_FIRMWARE, odd[i].empty() ? GM_HEALTH_PASS : GM_HEALTH_WARN, 0,
                        odd[i].empty() ? "VBIOS, firmware, product, partition modes and HBM size as on the other GPUs" : odd[i]);
     const std::string part = std::string(x.compute_partition[0] ? x.compute_partition : "-") + "/" + (x.memory_partition[0] ? x.memory_partition : "-");
-    r.text("%-3u %-13s %-22.22s %-14.14s %-9s %-5d %-14s %-11s %s\n", i, x.pci_bdf, x.name, x.vbios[0] ? x.vbios : "-", part.c_str(), x.numa_node, link.c_str(),
-           cap.c_str(), pages.c_str());
+    const std::string fabric = links_up < 0 || !links_wired ? "-" : strprintf_local("%d/%d", links_up, links_wired);
+    r.text("%-3u %-13s %-22.22s %-14.14s %-9s %-5d %-14s %-11s %-5s %s\n", i, x.pci_bdf, x.name, x.vbios[0] ? x.vbios : "-", part.c_str(), x.numa_node, link.c_str(),
+           cap.c_str(), fabric.c_str(), pages.c_str());
     arr += std::string(i ? "," : "") + "{\"gpu\":" + std::to_string(i) + ",\"pci_bdf\":" + jstr(x.pci_bdf) + ",\"name\":" + jstr(x.name) + ",\"vbios\":" + jstr(x.vbios) +
            ",\"firmware\":" + jstr(x.firmware) + ",\"compute_partition\":" + jstr(x.compute_partition) + ",\"memory_partition\":" + jstr(x.memory_partition) +
            ",\"numa_node\":" + std::to_string(x.numa_node) + ",\"link_gen\":" + std::to_string(cur_gen) + ",\"link_width\":" + std::to_string(cur_w) +
            ",\"link_max_gen\":" + std::to_string(max_gen) + ",\"link_max_width\":" + std::to_string(max_w) + ",\"power_cap_w\":" + jnum(x.power_cap_w) +
-           ",\"power_cap_default_w\":" + jnum(x.power_cap_default_w) + ",\"pages_pending\":" + jnum(pending < 0 ? NAN : pending) +
+           ",\"power_cap_default_w\":" + jnum(x.power_cap_default_w) + ",\"xgmi_links_up\":" + (links_up < 0 ? std::string("null") : std::to_string(links_up)) +
+           ",\"xgmi_links_wired\":" + std::to_string(links_wired) + ",\"pages_pending\":" + jnum(pending < 0 ? NAN : pending) +
            ",\"ecc_ue\":" + jnum(ue < 0 ? NAN : ue) + ",\"ecc_ce\":" + jnum(ce < 0 ? NAN : ce) + "}";
   }
   r.member("devices", arr + "]");

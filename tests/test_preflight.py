@@ -12,7 +12,7 @@ from conftest import bin_path
 DIAG = bin_path("gpumon-diag")
 pytestmark = pytest.mark.skipif(not os.path.exists(DIAG), reason="needs the built gpumon-diag")
 PASS, WARN, FAIL = 0, 10, 20
-PCIE, MEM, POWER, DRIVER, FIRMWARE = 1, 4, 32, 64, 128
+PCIE, XGMI, MEM, POWER, DRIVER, FIRMWARE = 1, 2, 4, 32, 64, 128
 
 
 def preflight(spec="gpus=8", *args, env=None):
@@ -31,17 +31,19 @@ def test_a_clean_node_passes_every_check_on_every_gpu():
     rc, doc, _ = preflight()
     assert rc == 0 and doc["result"] == "pass" and doc["scope"] == "node" and doc["node"]["gpus"] == 8
     assert len(doc["devices"]) == 8 and doc["devices"][3]["pci_bdf"] == "0000:35:00.0" and doc["devices"][0]["power_cap_w"] == 1400
-    for test, system in (("preflight_access", DRIVER), ("preflight_memory", MEM), ("preflight_power", POWER), ("preflight_uniform", FIRMWARE)):
+    for test, system in (("preflight_access", DRIVER), ("preflight_memory", MEM), ("preflight_power", POWER), ("preflight_uniform", FIRMWARE),
+                         ("preflight_fabric", XGMI)):
         v = by_gpu(doc, test)
         assert sorted(v) == list(range(8)), (test, sorted(v))
         assert all(x["health"] == PASS and x["system"] == system and x["pci_bdf"] == doc["devices"][g]["pci_bdf"] for g, x in v.items())
+    assert all(d["xgmi_links_up"] == 7 and d["xgmi_links_wired"] == 7 for d in doc["devices"])
     node = by_gpu(doc, "preflight_runtime")
     assert list(node) == [None] and node[None]["health"] == PASS and node[None]["system"] == DRIVER
 
 
 def test_seeded_faults_are_named_with_gpu_concern_and_subsystem():
     spec = ("gpus=8,at_start=bad_pages+gpu=2+pending=3;static+gpu=5+vbios=113-OLD+power_cap=1000;ecc+gpu=6+ue=2;"
-            "static+gpu=1+compute_partition=CPX")
+            "static+gpu=1+compute_partition=CPX;link_down+gpu=3+link=4")
     rc, doc, err = preflight(spec)
     assert rc == 1 and doc["result"] == "fail"
     mem, power, uniform = by_gpu(doc, "preflight_memory"), by_gpu(doc, "preflight_power"), by_gpu(doc, "preflight_uniform")
@@ -50,6 +52,10 @@ def test_seeded_faults_are_named_with_gpu_concern_and_subsystem():
     assert power[5]["health"] == WARN and "1000 W is under the default 1400 W" in power[5]["message"]
     assert uniform[5]["health"] == WARN and "113-OLD" in uniform[5]["message"] and "113-M3550101-100" in uniform[5]["message"]
     assert uniform[1]["health"] == WARN and "compute partition CPX" in uniform[1]["message"]
+    fabric = by_gpu(doc, "preflight_fabric")
+    assert fabric[3]["health"] == FAIL and fabric[3]["system"] == XGMI and fabric[3]["value"] == 6
+    assert "xGMI link 4 (to GPU " in fabric[3]["message"] and "6 of 7 links up" in fabric[3]["message"]
+    assert [g for g, v in fabric.items() if v["health"]] == [3] and doc["devices"][3]["xgmi_links_up"] == 6
     # everything else stays clean: a fault is charged to its GPU and its concern only
     assert [g for g, v in mem.items() if v["health"]] == [2, 6] and [g for g, v in power.items() if v["health"]] == [5]
     assert sorted(g for g, v in uniform.items() if v["health"]) == [1, 5]
@@ -87,7 +93,7 @@ def test_the_gpu_count_is_held_against_what_the_node_should_have():
     assert rc == 0
     # one GPU: nothing to compare it with
     rc, doc, _ = preflight("gpus=1")
-    assert rc == 0 and not by_gpu(doc, "preflight_uniform")
+    assert rc == 0 and not by_gpu(doc, "preflight_uniform") and not by_gpu(doc, "preflight_fabric")
     # a library that cannot be opened is a finding, not a crash
     rc, doc, _ = preflight("gpus=8,fail_init=1")
     assert rc == 1 and by_gpu(doc, "preflight_runtime")[None]["health"] == FAIL
