@@ -430,6 +430,28 @@ def test_gemm_split_along_k(diag, dev, dtype):
     assert torch.equal(got1, want1) and torch.equal(got2, want2)
 
 
+def test_gemm_random_shapes_through_the_automatic_schedule(tmp_path):
+    """Random M, N (multiples of 8; whole tiles for MX-fp8) and K-tile counts through whatever the planner picks for them,
+    each against the fp32 product, with a guard band and a second launch for the same bits (`scripts/gpu_gemm_fuzz.py`):
+    the pairings of ragged edges, odd K-tile counts and short last ranges that the fixed shapes above do not list."""
+    import json
+    import os
+    import subprocess
+    import sys
+    out = tmp_path / "fuzz.jsonl"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_gemm_fuzz.py"), "--cases", "240", "--seed", "5", "--out", str(out)],
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    summary = json.loads(r.stdout.strip().splitlines()[-1])
+    assert summary["cases"] == 240 and summary["failed"] == 0
+    rows = [json.loads(ln) for ln in out.read_text().splitlines()]
+    for dtype in ("bf16", "fp8", "mxfp8"):
+        seen = {(x["schedule"], x["splits"] > 1) for x in rows if x["dtype"] == dtype}
+        assert (0, False) in seen and any(split for _, split in seen), (dtype, seen)
+    assert {x["schedule"] for x in rows} >= {0, 9, 10}
+
+
 def test_mx_gemm_takes_an_odd_number_of_k_tiles(diag, dev):
     for (m, n, kt) in [(256, 512, 1), (512, 256, 3), (768, 256, 9)]:
         G = _Gemm(diag, dev, m, n, kt * 128, "mxfp8", seed=kt)
