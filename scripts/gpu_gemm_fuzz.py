@@ -7,7 +7,12 @@ along K on either tile size with a short last range).  Per case: relative error 
 behind C untouched, and the same bits from a second launch.  One JSON line per case in gpurun_out/gemm_fuzz.jsonl; the
 exit status is 1 when a case fails.
 
-    python scripts/gpu_gemm_fuzz.py [--cases 150] [--seed 1]
+With --soak SECONDS the same shapes go through the soak driver instead (operands of its own, its fp32 reference check,
+every launch summed in the kernel and every result re-read from memory): the summing forms of the kernels are other
+instantiations than the ones a plain launch runs, and a sum that came out differently from launch to launch at some
+shape would be reported to an operator as silent data corruption.
+
+    python scripts/gpu_gemm_fuzz.py [--cases 150] [--seed 1] [--soak 0.05]
 """
 import argparse
 import json
@@ -24,6 +29,7 @@ def main():
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="gpurun_out/gemm_fuzz.jsonl")
+    ap.add_argument("--soak", type=float, default=0.0, help="seconds per case through the soak driver instead of single launches")
     a = ap.parse_args()
     import torch
     from k8s_gpu_monitor_amd.ops import diag
@@ -58,6 +64,28 @@ def main():
             dtype = rnd.choice(["bf16", "fp8", "mxfp8"])
             kind, m, n, kt = shape(dtype)
             k = kt * (64 if dtype == "bf16" else 128)
+            if a.soak > 0:
+                schedule, splits = diag.gemm_plan(dtype, m, n, k)
+                row = {"case": case, "kind": kind, "dtype": dtype, "m": m, "n": n, "k": k, "schedule": schedule, "splits": splits}
+                try:
+                    r = diag.gemm_stress(dtype, m, n, k, seconds=a.soak, verify=True, check_every=1)
+                    row.update(launches=r["launches"], checked_in_kernel=r["checked_in_kernel"], checked_in_memory=r["checked_in_memory"],
+                               rel_err=r["max_rel_err"], sdc_mismatches=r["sdc_mismatches"])
+                    row["ok"] = (r["verified"] == 1 and r["sdc_mismatches"] == 0 and r["launches"] > 0 and r["max_rel_err"] < 6e-3
+                                 and r["checked_in_kernel"] == r["launches"] and r["checked_in_memory"] > 0)
+                except diag.DiagError as e:
+                    row.update(ok=False, error=str(e)[-300:])
+                out.write(json.dumps(row) + "\n")
+                out.flush()
+                key = f"{dtype} schedule {schedule}" + (f" x{splits}" if splits > 1 else "")
+                by_schedule[key] = by_schedule.get(key, 0) + 1
+                if not row["ok"]:
+                    failed += 1
+                    print("FAILED:", json.dumps(row), flush=True)
+                if time.time() - t_last > 20:
+                    print(f"{case + 1} of {a.cases} cases, {failed} failed", flush=True)
+                    t_last = time.time()
+                continue
             g = torch.Generator(device=dev).manual_seed(a.seed * 100003 + case)
             af, bf = torch.randn(m, k, device=dev, generator=g), torch.randn(n, k, device=dev, generator=g)
             kw = {}
@@ -103,7 +131,7 @@ def main():
                 print(f"{case + 1} of {a.cases} cases, {failed} failed", flush=True)
                 t_last = time.time()
             del ref, buf, c, c2, qa, qb
-    print(json.dumps({"cases": a.cases, "seed": a.seed, "failed": failed, "by_schedule": dict(sorted(by_schedule.items()))}), flush=True)
+    print(json.dumps({"cases": a.cases, "seed": a.seed, "soak_s": a.soak, "failed": failed, "by_schedule": dict(sorted(by_schedule.items()))}), flush=True)
     return 1 if failed else 0
 
 
