@@ -450,6 +450,12 @@ def test_gemm_random_shapes_through_the_automatic_schedule(tmp_path):
         seen = {(x["schedule"], x["splits"] > 1) for x in rows if x["dtype"] == dtype}
         assert (0, False) in seen and any(split for _, split in seen), (dtype, seen)
     assert {x["schedule"] for x in rows} >= {0, 9, 10}
+    # the soak's kernels are other instantiations (they sum what they store): no shape may make that sum wander
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_gemm_fuzz.py"), "--cases", "60", "--seed", "7", "--soak", "0.03",
+                        "--out", str(out)], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    summary = json.loads(r.stdout.strip().splitlines()[-1])
+    assert summary["cases"] == 60 and summary["failed"] == 0
 
 
 def test_mx_gemm_takes_an_odd_number_of_k_tiles(diag, dev):
