@@ -69,6 +69,50 @@ def test_stream_kernels_match_torch(diag, dev, n, nt):
     assert sink.double().sum().item() == pytest.approx(want, abs=1e-3 * math.sqrt(n) + 1e-3)
 
 
+def test_stream_and_memtest_stay_inside_their_buffers_at_random_sizes(diag, dev):
+    """Sizes drawn at random (any multiple of 16 bytes, from one vector to 192 MiB), every buffer between two guard bands:
+    a launch plan whose last workgroup, last pass or vector tail reaches past the end writes into the band."""
+    import random
+    rnd = random.Random(20)
+    guard = 1024
+    sizes = [4, 8, 12, 252, 260] + [rnd.randrange(4, 1 << rnd.randrange(4, 26), 4) for _ in range(25)] + [48 * (1 << 20) - 4]
+    for n in sizes:
+        g = torch.Generator(device=dev).manual_seed(n)
+        raw = [torch.full((n + 2 * guard,), 7.0, device=dev) for _ in range(3)]
+        a, b, c = (x[guard:guard + n] for x in raw)
+        a0, b0 = torch.randn(n, device=dev, generator=g), torch.randn(n, device=dev, generator=g)
+
+        def bands_intact():
+            return all(bool((x[:guard] == 7.0).all()) and bool((x[guard + n:] == 7.0).all()) for x in raw)
+
+        for kernel in ("copy", "add", "triad", "scale", "write"):
+            a.copy_(a0), b.copy_(b0), c.fill_(0.5)
+            diag.hbm_stream_launch(kernel, a.data_ptr(), b.data_ptr(), c.data_ptr(), 1.75, n, "auto", _stream())
+            torch.cuda.synchronize()
+            assert bands_intact(), (kernel, n)
+            if kernel == "copy":
+                assert torch.equal(c, a0), n
+            elif kernel == "add":
+                assert torch.equal(c, a0 + b0), n
+            elif kernel == "triad":
+                assert torch.allclose(a, b0 + 1.75 * 0.5, rtol=1e-6, atol=1e-6), n
+            elif kernel == "scale":
+                assert torch.equal(b, torch.full_like(b, 1.75 * 0.5)), n
+            else:
+                assert torch.equal(a, torch.full_like(a, 1.75)), n
+        words = n // 2  # the same bytes as 64-bit words; the memtest takes an even number of them
+        if words % 2 == 0 and words:
+            for pattern in ("address", "random", "walking_ones"):
+                if pattern not in diag.PATTERNS:
+                    continue
+                raw[0].fill_(7.0)
+                diag.memtest_fill(a.data_ptr(), words, pattern, seed=5, stream=_stream())
+                errs, log = diag.memtest_verify(a.data_ptr(), words, pattern, seed=5, stream=_stream())
+                torch.cuda.synchronize()
+                assert errs == 0 and bands_intact(), (pattern, n)
+                assert not bool((a.view(torch.int64) == torch.tensor(7.0).repeat(2).view(torch.int64).item()).all()), (pattern, n)
+
+
 def test_stream_rejects_bad_arguments(diag, dev):
     a = torch.zeros(1024, device=dev)
     with pytest.raises(diag.DiagError):
